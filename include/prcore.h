@@ -1,0 +1,155 @@
+/*
+ * prcore.h -- C ABI of libprcore.so, the MI355X (gfx950) range-Doppler core.
+ *
+ * The reference (Max-Manning/passiveRadar) is pure Python and has no FFI layer; its
+ * boundary for this path is the Python function level.  Each entry
+ * point below replaces one reference function (or the SciPy/NumPy sequence inside it) and
+ * is what a reference-side ctypes stub binds (INTEGRATION.md shows the stubs).  Citations
+ * are file:line in the reference checkout.
+ *
+ * Conventions
+ *   - extern "C", plain ints / pointers / POD structs; no C++ types, no exceptions cross.
+ *   - complex64 samples are interleaved float pairs (re, im): `const void*` to 8-byte items.
+ *   - all data pointers are DEVICE pointers unless the name ends in `_host`.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Work is enqueued
+ *     asynchronously; nothing synchronises unless stated.
+ *   - caller owns inputs and outputs; the library owns plans and their workspaces.
+ *   - every function returns PRC_OK (0) or a negative prc_status; prc_last_error() gives a
+ *     thread-local message.  The Python layer maps PRC_ESHAPE to ValueError to keep the
+ *     reference's error convention (range_doppler_processing.py:46-49, clutter_removal.py:28-29).
+ *   - a plan may be used by one thread at a time (internally serialised by a mutex);
+ *     different plans may be used concurrently from different threads (dask-style callers).
+ */
+#ifndef PRCORE_H
+#define PRCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRC_VERSION 100
+
+typedef enum prc_status {
+    PRC_OK = 0,
+    PRC_EINVAL = -1,       /* bad argument (null pointer, non-positive size, ...)           */
+    PRC_ESHAPE = -2,       /* length mismatch -> ValueError on the Python side             */
+    PRC_EHIP = -3,         /* a HIP runtime call failed (no GPU, OOM, launch failure)      */
+    PRC_EROCFFT = -4,      /* a rocFFT call failed                                          */
+    PRC_EUNSUPPORTED = -5  /* valid request outside what this build implements              */
+} prc_status;
+
+/* ---- library / device ------------------------------------------------------------- */
+int prc_version(void);
+const char* prc_last_error(void);
+int prc_device_count(int* count);
+int prc_set_device(int device);
+/* Device-memory helpers for hosts that do not bring their own allocator (the NumPy-facing
+ * drop-in functions use these; torch-based callers pass tensor.data_ptr() instead). */
+int prc_malloc(void** dptr, size_t bytes);
+int prc_free(void* dptr);
+int prc_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int prc_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int prc_memset(void* dptr, int value, size_t bytes, void* stream);
+int prc_stream_sync(void* stream);
+
+/* ---- cross-ambiguity surface: fast_xambg (range_doppler_processing.py:12-90) -------- */
+typedef enum prc_caf_method {
+    PRC_CAF_AUTO = 0,
+    PRC_CAF_DIRECT = 1,    /* time-domain lagged products in LDS tiles (any decimation FIR) */
+    PRC_CAF_FFT = 2        /* per-segment FFT correlation held in LDS/registers (boxcar FIR) */
+} prc_caf_method;
+
+typedef enum prc_doppler_method {
+    PRC_DOPPLER_AUTO = 0,
+    PRC_DOPPLER_ROCFFT = 1, /* batched 1-D rocFFT over the slow-time axis (any freq_bins)     */
+    PRC_DOPPLER_FUSED = 2   /* in-LDS radix FFT + fftshift + transpose (power-of-two bins)    */
+} prc_doppler_method;
+
+typedef struct prc_caf_desc {
+    int64_t n;             /* samples per CPI after zero padding = inputLen (:52-55)         */
+    int32_t range_bins;    /* rangeBins; the surface has range_bins+1 columns (:64)          */
+    int32_t freq_bins;     /* freqBins; decimation q = (int)(n / freq_bins) (:61)            */
+    int32_t max_frames;    /* workspace is sized for this many frames per execute           */
+    int32_t method;        /* prc_caf_method                                                 */
+    int32_t doppler;       /* prc_doppler_method                                             */
+    int32_t ntaps;         /* 0: boxcar ones(q+1) (shortFilt=True, :72); else length of taps */
+    const float* taps_host;/* HOST pointer, copied at plan creation (shortFilt=False, :76)   */
+} prc_caf_desc;
+
+typedef struct prc_caf_plan prc_caf_plan;
+
+int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* desc);
+int prc_caf_plan_destroy(prc_caf_plan* plan);
+/* Which kernels the plan resolved AUTO to (prc_caf_method / prc_doppler_method values). */
+int prc_caf_plan_info(const prc_caf_plan* plan, int32_t* method, int32_t* doppler,
+                      int64_t* workspace_bytes);
+
+/* out[f][k] for each frame: complex64 [nframes][freq_bins][range_bins+1], C order; frame b
+ * reads ref/srv at element offset b*frame_stride (frame_stride = n for dense batches, = n/2
+ * for the 50 %-overlapped frames of main.py:178-194).  Samples with index >= n_valid inside
+ * a frame are taken as zero (the zero-pad branch :52-55); pass n_valid = n otherwise.
+ * window: float32[n] device pointer or NULL (:83-84).  Column k <-> delay range_bins-k,
+ * rows fftshift-ed, circular wrap of srv within the frame (:82) -- exactly as the reference. */
+int prc_caf_execute(prc_caf_plan* plan, const void* ref, const void* srv, int64_t frame_stride,
+                    int64_t n_valid, const float* window, void* out, int32_t nframes,
+                    void* stream);
+/* Stages timed separately by bench.py (same arguments; `segment` writes the plan's internal
+ * slow-time buffer, `doppler` turns it into out). */
+int prc_caf_execute_segments(prc_caf_plan* plan, const void* ref, const void* srv,
+                             int64_t frame_stride, int64_t n_valid, const float* window,
+                             int32_t nframes, void* stream);
+int prc_caf_execute_doppler(prc_caf_plan* plan, void* out, int32_t nframes, void* stream);
+
+/* ---- block least-squares clutter cancellers (clutter_removal.py) ------------------- */
+typedef struct prc_ls_desc {
+    int64_t n;             /* samples per block (chunk)                                     */
+    int32_t filter_len;    /* filterLen                                                     */
+    int32_t peek;          /* non-causal taps (default 10 in the reference)                 */
+    int32_t circular;      /* 0: LS_Filter_Toeplitz semantics (:109-160: circular peek shift,
+                              linear correlations, linear FIR); 1: LS_Filter semantics (:6-56:
+                              circular data matrix => circular correlations and FIR)        */
+    int32_t max_blocks;    /* workspace is sized for this many independent blocks           */
+    int32_t method;        /* 0 auto, 1 direct (time-domain), 2 FFT overlap-save            */
+} prc_ls_desc;
+
+typedef struct prc_ls_plan prc_ls_plan;
+
+int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* desc);
+int prc_ls_plan_destroy(prc_ls_plan* plan);
+
+/* LS_Filter_Multiple (:162-187) on nblocks independent blocks: for each Doppler bin in
+ * order, cancel the (frequency-shifted, float32 phase -- signal_utils.py:24-27) reference from
+ * the previous bin's output.  nbins = 1, bins = {0} is LS_Filter_Toeplitz; with
+ * desc.circular = 1 and reg it is LS_Filter.  block b reads ref/srv at b*stride elements and
+ * writes complex64 out at b*out_stride.  taps_out: optional complex128 [nblocks][T] (device)
+ * taps of the LAST bin (return_filter=True), T = filter_len + peek.
+ * doppler_bins_host: HOST array of nbins doubles (Hz). reg is added to the Gram diagonal. */
+int prc_ls_execute(prc_ls_plan* plan, const void* ref, const void* srv, int64_t stride,
+                   void* out, int64_t out_stride, int32_t nblocks, double sample_rate,
+                   const double* doppler_bins_host, int32_t nbins, double reg,
+                   void* taps_out, void* stream);
+
+/* ---- NLMS_filter (clutter_removal.py:189-249) ---------------------------------------- */
+/* nstreams independent sample-recursive filters, one wavefront each.  taps_in: optional
+ * complex64 [nstreams][T] initial taps (initialTaps), NULL = zeros.  taps_out: optional
+ * complex64 [nstreams][T].  out: complex64, zero outside [filter_len, n-peek). */
+int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int64_t stride,
+                     int32_t filter_len, int32_t peek, float mu, const void* taps_in,
+                     void* out, int64_t out_stride, void* taps_out, int32_t nstreams,
+                     void* stream);
+
+/* ---- helpers that sit on the path (signal_utils.py) ---------------------------------- */
+/* xcorr (:29-32): z[i] = sum_n s1[n] conj(s2[n-(i-nlead)]), i = 0..nlag+nlead; complex64 out. */
+int prc_xcorr(const void* s1, const void* s2, int64_t n, int32_t nlead, int32_t nlag,
+              void* out, void* stream);
+/* frequency_shift (:24-27): y[n] = x[n] exp(j(fl32 phase ramp + phase_offset)). */
+int prc_frequency_shift(const void* x, void* y, int64_t n, double fc, double fs,
+                        double phase_offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRCORE_H */

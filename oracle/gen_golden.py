@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE's own modules (build container only).
+
+    python oracle/gen_golden.py [--big]
+
+The reference (pure Python) is imported from /root/reference; it never travels to
+the GPU box -- only the vectors written here do.  Inputs come from
+passiveradar_amd.scene (seeded Philox) and are stored alongside the outputs for
+the small cases; the big cases store the seed + scene parameters only.
+
+SciPy-1.15 artefact: ``scipy.signal.decimate`` calls ``dlti._as_zpk()`` -> ``np.roots`` on the
+(q+1)-tap boxcar for every lag.  That is O(q^3) per lag and changes nothing in the
+output (checked below, bit for bit, on a small case).  For the big cases (q=1024..4882) the
+root finder is short-circuited *in this process only* by reporting "no poles" for a
+denominator of 1; the reference files are not modified.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+warnings.filterwarnings("ignore")
+
+import numpy as np
+import scipy
+import scipy.signal as signal
+
+from passiveRadar import range_doppler_processing as ref_rd      # noqa: E402
+from passiveRadar import clutter_removal as ref_cr               # noqa: E402
+from passiveRadar import signal_utils as ref_su                  # noqa: E402
+from passiveRadar import config as ref_cfg                       # noqa: E402
+from passiveradar_amd import scene                               # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+META = {"numpy": np.__version__, "scipy": scipy.__version__,
+        "generator": "oracle/gen_golden.py", "reference": "Max-Manning/passiveRadar @ /root/reference"}
+
+
+class no_root_finding:
+    """Context manager: make dlti(num, 1)._as_zpk() report an FIR without calling np.roots."""
+
+    def __enter__(self):
+        from scipy.signal._ltisys import TransferFunction, ZerosPolesGain
+        self.cls = TransferFunction
+        self.orig = TransferFunction.to_zpk
+        orig = self.orig
+
+        def to_zpk(tf):
+            den = np.atleast_1d(tf.den)
+            if den.size == 1 and den[0] == 1:
+                return ZerosPolesGain(np.zeros(0), np.zeros(0), 1.0, **tf._dt_dict)
+            return orig(tf)
+        TransferFunction.to_zpk = to_zpk
+        return self
+
+    def __exit__(self, *a):
+        self.cls.to_zpk = self.orig
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, meta=json.dumps(META), **arrays)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1e3:.1f} kB")
+
+
+def caf_cases():
+    print("fast_xambg small cases")
+    cases = [  # name, N_in, R, F, inputLen, window spec, shortFilt, srv dtype
+        ("p2", 4096, 7, 64, 4096, "none", True, "c64"),
+        ("p2_kaiser_arr", 4096, 7, 64, 4096, "array", True, "c64"),
+        ("p2_kaiser_tuple", 4096, 7, 64, 4096, "tuple", True, "c64"),
+        ("oddq", 6000, 6, 64, 6000, "array", True, "c64"),
+        ("oddq_p1", 6001, 6, 64, 6001, "none", True, "c64"),
+        ("nondiv", 4100, 3, 64, 4100, "array", True, "c64"),
+        ("small", 2401, 3, 16, 2401, "tuple", True, "c64"),
+        ("bigq", 9375, 3, 2, 9375, "none", True, "c64"),
+        ("padded", 4000, 7, 64, 4096, "tuple", True, "c64"),
+        ("longfilt", 4096, 7, 64, 4096, "array", False, "c64"),
+        ("srv128", 4096, 7, 64, 4096, "array", True, "c128"),
+        ("lags_gt_q", 4096, 40, 256, 4096, "array", True, "c64"),   # R > q=16
+    ]
+    for i, (name, n, R, F, ilen, wspec, short, sdt) in enumerate(cases):
+        a, s = scene.make_scene(n, 8000.0, R, scene.scene_seed(90, i),
+                                targets=((max(R - 2, 1), 31.0, 0.05),))
+        if sdt == "c128":
+            s = s.astype(np.complex128)
+        if wspec == "none":
+            w = None
+        elif wspec == "array":
+            w = signal.get_window(("kaiser", 5.0), ilen)
+        else:
+            w = ("kaiser", 5.0)
+        out = ref_rd.fast_xambg(a, s, R, F, ilen, w, short)
+        save("caf_" + name, ref=a, srv=s, R=R, F=F, inputLen=ilen,
+             window=(np.zeros(0) if w is None else (w if wspec == "array" else np.array([5.0]))),
+             wspec=wspec, shortFilt=short, out=out)
+
+
+def artefact_check():
+    a, s = scene.make_scene(4096, 8000.0, 7, scene.scene_seed(91))
+    w = signal.get_window(("kaiser", 5.0), 4096)
+    x0 = ref_rd.fast_xambg(a, s, 7, 64, 4096, w)
+    with no_root_finding():
+        x1 = ref_rd.fast_xambg(a, s, 7, 64, 4096, w)
+    assert np.array_equal(x0, x1), "root-finding bypass changed the output"
+    print("root-finding bypass is bit-identical on the small case")
+
+
+def helper_cases():
+    print("xcorr / frequency_shift")
+    a, s = scene.make_scene(5000, 8000.0, 20, scene.scene_seed(92))
+    save("xcorr", s1=a, s2=s,
+         z_0_20=ref_su.xcorr(a, s, 0, 20), z_7_0=ref_su.xcorr(a, s, 7, 0),
+         z_3_9=ref_su.xcorr(a, s, 3, 9), z_auto=ref_su.xcorr(a, a, 0, 15))
+    x, _ = scene.make_scene(200000, 262184.87, 8, scene.scene_seed(93))
+    dec = slice(None, None, 16)          # outputs stored decimated; x is regenerated from the seed
+    save("freqshift", seed=scene.scene_seed(93), n=200000, fs=262184.87, x_head=x[:64], stride=16,
+         y_p1=ref_su.frequency_shift(x, 1, 262184.87)[dec], y_m2=ref_su.frequency_shift(x, -2, 262184.87)[dec],
+         y_f=ref_su.frequency_shift(x, 37.5, 262184.87)[dec],
+         y_ph=ref_su.frequency_shift(x, 80.0, 262184.87, 0.3)[dec])
+
+
+def ls_cases():
+    print("LS filters")
+    n, L = 12000, 30
+    a, s = scene.make_scene(n, 262184.0, L, scene.scene_seed(94))
+    o, t = ref_cr.LS_Filter_Toeplitz(a, s, L, return_filter=True)
+    save("ls_toeplitz_white", ref=a, srv=s, L=L, peek=10, out=o, taps=t)
+    o, t = ref_cr.LS_Filter_Toeplitz(a, s, L, peek=0, return_filter=True)
+    save("ls_toeplitz_peek0", ref=a, srv=s, L=L, peek=0, out=o, taps=t)
+    ac, sc = scene.make_scene(n, 262184.0, L, scene.scene_seed(95), colour=(1.0, 0.5, 0.2))
+    o, t = ref_cr.LS_Filter_Toeplitz(ac, sc, L, return_filter=True)
+    save("ls_toeplitz_coloured", ref=ac, srv=sc, L=L, peek=10, out=o, taps=t)
+    o = ref_cr.LS_Filter_Multiple(a, s, L, 262184.0, [0, 1, -1, 2, -2])
+    save("ls_multiple", ref=a, srv=s, L=L, fs=262184.0, bins=np.array([0, 1, -1, 2, -2]), out=o)
+    n2 = 8192
+    a2, s2 = scene.make_scene(n2, 262184.0, L, scene.scene_seed(96))
+    o, t = ref_cr.LS_Filter(a2, s2, L, return_filter=True)
+    save("ls_direct", ref=a2, srv=s2, L=L, reg=1.0, peek=10, out=o, taps=t)
+    o, t = ref_cr.LS_Filter(a2, s2, L, reg=0.25, peek=3, return_filter=True)
+    save("ls_direct_reg", ref=a2, srv=s2, L=L, reg=0.25, peek=3, out=o, taps=t)
+
+
+def nlms_cases():
+    print("NLMS")
+    n, L = 4000, 20
+    a, s = scene.make_scene(n, 262184.0, L, scene.scene_seed(97))
+    o, t = ref_cr.NLMS_filter(a, s, L, 0.05, returnFilter=True)
+    save("nlms", ref=a, srv=s, L=L, mu=0.05, peek=10, out=o, taps=t)
+    o2, t2 = ref_cr.NLMS_filter(a, s, 999, 0.02, initialTaps=t.copy(), returnFilter=True)
+    save("nlms_warm", ref=a, srv=s, mu=0.02, peek=10, initialTaps=t, out=o2, taps=t2)
+    o3, t3 = ref_cr.NLMS_filter(a, s, 70, 0.08, peek=4, returnFilter=True)     # T=74 > one wave
+    save("nlms_t74", ref=a, srv=s, L=70, mu=0.08, peek=4, out=o3, taps=t3)
+
+
+def config_cases():
+    print("getConfiguration")
+    import tempfile
+    import yaml
+    d = ref_cfg.getConfiguration("/root/reference/PRconfig.yaml")
+    with open(os.path.join(GOLD, "config_prconfig.json"), "w") as fh:
+        json.dump(d, fh, indent=1, sort_keys=True)
+    base = yaml.safe_load(open("/root/reference/PRconfig.yaml"))
+    base.update(cpi_seconds_nominal=1.0, max_doppler_nominal=128.0, max_range_nominal=292.7)
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as fh:
+        yaml.safe_dump(base, fh)
+    d1 = ref_cfg.getConfiguration(fh.name)
+    os.unlink(fh.name)
+    with open(os.path.join(GOLD, "config_cfg1.json"), "w") as fh:
+        json.dump({"yaml_overrides": {"cpi_seconds_nominal": 1.0, "max_doppler_nominal": 128.0,
+                                      "max_range_nominal": 292.7}, "derived": d1},
+                  fh, indent=1, sort_keys=True)
+
+
+def stream_case():
+    """main.py:169-194 emulated in plain NumPy around the two imported reference functions."""
+    print("stream (block pipeline) case")
+    C, R, F, nch = 8192, 16, 64, 6
+    cpi = 2 * C
+    fs = 262184.0
+    a, s = scene.make_stream(nch, C, fs, R, scene.scene_seed(98))
+    cleaned = np.concatenate([
+        ref_cr.LS_Filter_Multiple(a[i * C:(i + 1) * C], s[i * C:(i + 1) * C], R, fs, [0, 1, -1, 2, -2])
+        for i in range(nch)])
+    depth = cpi // 4
+    pad = np.zeros(depth)
+    ap = np.concatenate((pad, a, pad))
+    sp = np.concatenate((pad, cleaned, pad))
+    w = signal.get_window(("kaiser", 5.0), cpi)
+    frames = [ref_rd.fast_xambg(ap[i * C:i * C + cpi], sp[i * C:i * C + cpi], R, F, cpi, w)
+              for i in range(nch)]
+    save("stream", ref=a, srv=s, C=C, R=R, F=F, fs=fs, cleaned=cleaned.astype(np.complex64),
+         out=np.concatenate(frames, axis=2))
+
+
+def big_cases():
+    print("big CAF cases (root finder short-circuited)")
+    with no_root_finding():
+        # config 1: N=262144, R=256, F=256
+        n, R, F, fs = 262144, 256, 256, 262184.87
+        a, s = scene.make_scene(n, fs, R, scene.scene_seed(1))
+        w = signal.get_window(("kaiser", 5.0), n)
+        t0 = time.time()
+        out = ref_rd.fast_xambg(a, s, R, F, n, w)
+        print(f"  cfg1 {time.time() - t0:.1f}s")
+        save("caf_cfg1", seed=scene.scene_seed(1), N=n, R=R, F=F, fs=fs, out=out)
+        # config 2: N=2.4e6, R=256, F=512
+        n, R, F, fs = 2400000, 256, 512, 2.4e6
+        a, s = scene.make_scene(n, fs, R, scene.scene_seed(2))
+        w = signal.get_window(("kaiser", 5.0), n)
+        t0 = time.time()
+        out = ref_rd.fast_xambg(a, s, R, F, n, w)
+        print(f"  cfg2 {time.time() - t0:.1f}s")
+        save("caf_cfg2", seed=scene.scene_seed(2), N=n, R=R, F=F, fs=fs, out=out)
+        # config 3: N=5e6, R=1024, F=1024 -- store a decimated digest (8.4 MB is not "small")
+        n, R, F, fs = 5000000, 1024, 1024, 1.0e7
+        a, s = scene.make_scene(n, fs, R, scene.scene_seed(3))
+        w = signal.get_window(("kaiser", 5.0), n)
+        t0 = time.time()
+        out = ref_rd.fast_xambg(a, s, R, F, n, w)
+        print(f"  cfg3 {time.time() - t0:.1f}s")
+        sub = out[::8, ::8, 0]
+        mag = np.abs(out[:, :, 0])
+        top = np.argsort(mag.ravel())[-64:]
+        save("caf_cfg3_digest", seed=scene.scene_seed(3), N=n, R=R, F=F, fs=fs,
+             sub=sub, top_idx=top, top_val=out[:, :, 0].ravel()[top],
+             col_sums=out[:, :, 0].sum(axis=0), row_sums=out[:, :, 0].sum(axis=1),
+             peak=mag.max())
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", action="store_true", help="also generate the cfg1/2/3 CAF goldens (minutes)")
+    ap.add_argument("--only-big", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    if not args.only_big:
+        artefact_check()
+        caf_cases()
+        helper_cases()
+        ls_cases()
+        nlms_cases()
+        config_cases()
+        stream_case()
+    if args.big or args.only_big:
+        big_cases()

@@ -1,0 +1,369 @@
+"""CPU oracle for the range-Doppler hot path -- TEST INFRASTRUCTURE ONLY.
+
+This module is a closed-form NumPy restatement of what the reference computes on
+the path named by BASELINE.json's north_star.  It is the *checker*: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import it.  Nothing under ``passiveradar_amd/`` imports it, and the product
+path raises when the HIP library is missing instead of falling back to this.
+
+Parity pin: the reference ships no tests or golden vectors, so
+the pin is made by us: ``oracle/gen_golden.py`` imports the reference's own
+modules in the build container and writes ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks every function below against them.
+Third-party arithmetic on the path lives in SciPy 1.15.3 / NumPy 2.2.6 (not
+pinned by the reference, ``environment.yaml:5-16``); the SciPy calls the
+reference makes are restated here in closed form:
+
+* ``scipy.signal.decimate(x, q, ftype=dlti(h,1))`` (zero_phase=True) ==
+  ``resample_poly(x, 1, q, window=h)`` == ``y[j] = sum_m h[m] x[j*q + (len(h)-1)//2 - m]``
+  with zeros outside ``[0, N)`` and ``ceil(N/q)`` outputs, accumulated in
+  complex128.
+* ``scipy.signal.correlate(s1, pad(s2,(nlag,nlead)), 'valid')`` ==
+  ``z[i] = sum_n s1[n] conj(s2[n-(i-nlead)])``.
+* ``scipy.linalg.solve_toeplitz(c, b)`` == Levinson recursion on the Hermitian
+  Toeplitz matrix with first column ``c`` (complex128).
+
+Each function cites the reference lines it follows (paths relative to the
+reference checkout).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = [
+    "decimation_taps", "caf_segment_sums", "fast_xambg", "fast_xambg_libcalls",
+    "direct_xambg", "xcorr", "frequency_shift", "levinson_hermitian",
+    "LS_Filter_Toeplitz", "LS_Filter_Multiple", "LS_Filter", "NLMS_filter",
+    "overlap_frames", "process_stream",
+]
+
+
+# --------------------------------------------------------------------------
+# CAF  (range_doppler_processing.py:12-90)
+# --------------------------------------------------------------------------
+
+def decimation_taps(q: int, shortFilt: bool = True) -> np.ndarray:
+    """Decimation FIR the reference builds at range_doppler_processing.py:69-78.
+
+    shortFilt -> ones(q+1) (:72); otherwise firwin(10q+1, 1/q, 'flattop') (:76).
+    """
+    if shortFilt:
+        return np.ones(q + 1, dtype=np.float64)
+    from scipy.signal import firwin
+    return firwin(10 * q + 1, 1.0 / q, window="flattop")
+
+
+def _resolve_window(window, n):
+    # range_doppler_processing.py:57-58 -- str/tuple windows go through get_window
+    if isinstance(window, (tuple, str)):
+        from scipy.signal import get_window
+        return get_window(window, n)
+    return window
+
+
+def caf_segment_sums(ref, srv, rangeBins, freqBins, window=None, taps=None):
+    """Lagged conjugate product + decimating FIR, before the Doppler FFT.
+
+    Follows range_doppler_processing.py:61-86.  Returns y[F, R+1] complex128 with
+    y[j, k] = sum_m h[m] * p_k[j*q + half - m],  p_k[n] = ref[n] conj(srv[(n+R-k) mod N]) w[n]
+    (p_k is rounded to complex64 as the reference's array arithmetic does).
+    """
+    ref = np.asarray(ref)
+    srv = np.asarray(srv)
+    N = ref.shape[0]
+    q = int(N / freqBins)                                  # :61
+    h = decimation_taps(q) if taps is None else np.asarray(taps, dtype=np.float64)
+    half = (h.size - 1) // 2
+    boxcar = bool(np.all(h == 1.0))
+    y = np.zeros((freqBins, rangeBins + 1), dtype=np.complex128)
+    sconj = np.conj(srv)                                   # :67
+    centres = np.arange(freqBins, dtype=np.int64) * q
+    lo = centres + half - (h.size - 1)                     # first sample of each window
+    hi = centres + half                                    # last sample (inclusive)
+    for k in range(rangeBins + 1):
+        ell = rangeBins - k                                # delay in samples
+        # np.roll(conj(srv), -ell)[n] == conj(srv[(n+ell) mod N])            (:82)
+        prod = np.concatenate((sconj[ell:], sconj[:ell])) * ref
+        if window is not None:
+            prod = prod * window                           # :83-84
+        if prod.dtype != np.complex128:
+            # the reference keeps complex64 when srv is complex64 and the window is
+            # applied in place (:84); upfirdn then accumulates in complex128.
+            prod = prod.astype(np.result_type(ref.dtype, srv.dtype)).astype(np.complex128)
+        if boxcar:
+            cs = np.concatenate(([0.0], np.cumsum(prod)))
+            a = np.clip(lo, 0, N)
+            b = np.clip(hi + 1, 0, N)
+            y[:, k] = cs[b] - cs[a]
+        else:
+            full = np.convolve(prod, h)                    # full[t] = sum_m h[m] prod[t-m]
+            idx = centres + half
+            ok = idx < full.size
+            y[ok, k] = full[idx[ok]]
+    return y
+
+
+def fast_xambg(refChannel, srvChannel, rangeBins, freqBins, inputLen=None,
+               window=None, shortFilt=True):
+    """Closed-form restatement of range_doppler_processing.py:12-90.
+
+    Output (freqBins, rangeBins+1, 1) complex64: column k <-> delay R-k, rows are
+    fftshift(FFT over the decimated slow-time axis) computed in single precision
+    (scipy.fftpack.fft on complex64, :6,:89).
+    """
+    refChannel = np.asarray(refChannel)
+    srvChannel = np.asarray(srvChannel)
+    if refChannel.shape != srvChannel.shape:               # :46-49
+        raise ValueError("Input vectors must have the same length")
+    if inputLen is not None and refChannel.shape[0] != inputLen:   # :52-55
+        pad = inputLen - refChannel.shape[0]
+        refChannel = np.pad(refChannel, (0, pad))
+        srvChannel = np.pad(srvChannel, (0, pad))
+    window = _resolve_window(window, inputLen)
+    q = int(refChannel.shape[0] / freqBins)
+    y = caf_segment_sums(refChannel, srvChannel, rangeBins, freqBins, window,
+                         decimation_taps(q, shortFilt))
+    y64 = y.astype(np.complex64)                           # store into complex64 xambg (:64,:86)
+    from scipy.fft import fft as _fft                      # single precision for complex64 input
+    X = np.fft.fftshift(_fft(y64, axis=0), axes=0)         # :89
+    return X.reshape(freqBins, rangeBins + 1, 1).astype(np.complex64)
+
+
+def fast_xambg_libcalls(ref, srv, rangeBins, freqBins, window=None):
+    """Same result as fast_xambg, but issuing the library operations the reference
+    issues per lag (roll, multiply, window, polyphase boxcar decimation, FFT) with
+    the SciPy-1.15 ``dlti._as_zpk -> np.roots`` artefact left out (SURVEY.md section 0:
+    the artefact does not change the output).  This is the honest CPU cost of the
+    reference path and is what bench.py times as ``cpu_baseline``.
+    """
+    from scipy.signal import resample_poly
+    from scipy.fft import fft as _fft
+    n = ref.shape[0]
+    q = int(n / freqBins)
+    box = np.ones(q + 1)
+    out = np.empty((freqBins, rangeBins + 1), dtype=np.complex64)
+    sc = np.conjugate(srv)
+    for col in range(rangeBins + 1):
+        shifted = np.roll(sc, col - rangeBins)
+        shifted *= ref
+        if window is not None:
+            shifted *= window
+        out[:, col] = resample_poly(shifted, 1, q, window=box)[:freqBins]
+    return np.fft.fftshift(_fft(out, axis=0), axes=0).reshape(freqBins, rangeBins + 1, 1)
+
+
+def direct_xambg(refChannel, srvChannel, rangeBins, freqBins, sampleRate):
+    """Time-domain CAF, range_doppler_processing.py:93-124 (independent peak check only).
+
+    Row i is Doppler (i - F/2)/CPI (not mirrored), column k is delay R-k.
+    """
+    ref = np.asarray(refChannel)
+    srv = np.asarray(srvChannel)
+    if ref.shape != srv.shape:
+        raise ValueError("Input vectors must have the same length")
+    cpi = ref.shape[0] / sampleRate                        # :110
+    out = np.zeros((freqBins, rangeBins + 1, 1), dtype=np.complex64)
+    for i in range(freqBins):
+        df = (i - 0.5 * freqBins) / cpi                    # :118
+        out[i, :, 0] = xcorr(frequency_shift(ref, df, sampleRate), srv, rangeBins, 0)  # :120-122
+    return out
+
+
+# --------------------------------------------------------------------------
+# helpers from signal_utils.py that sit on the path
+# --------------------------------------------------------------------------
+
+def xcorr(s1, s2, nlead, nlag):
+    """signal_utils.py:29-32: z[i] = sum_n s1[n] conj(s2[n - (i - nlead)]), i = 0..nlag+nlead,
+    terms outside either array dropped.  Accumulated in complex128, returned in the
+    inputs' result type (complex64 for complex64 inputs, as SciPy's direct method does)."""
+    s1 = np.asarray(s1)
+    s2 = np.asarray(s2)
+    n1, n2 = s1.shape[0], s2.shape[0]
+    out = np.zeros(nlag + nlead + 1, dtype=np.complex128)
+    a = s1.astype(np.complex128)
+    b = s2.astype(np.complex128)
+    for i in range(out.size):
+        d = i - nlead                    # pair s1[n] with s2[n-d]
+        n_lo = max(0, d)
+        n_hi = min(n1, n2 + d)
+        if n_hi > n_lo:
+            out[i] = np.vdot(b[n_lo - d:n_hi - d], a[n_lo:n_hi])
+    return out.astype(np.result_type(s1.dtype, s2.dtype, np.complex64))
+
+
+def frequency_shift(x, fc, Fs, phase_offset=0):
+    """signal_utils.py:24-27.  The sample index is held as complex64, so for scalar
+    phase_offset the whole phase ramp is evaluated in float32 (NumPy-2 weak-scalar
+    promotion); this restatement spells the float32 steps out:
+        ph[n] = fl32( fl32( fl32(2*pi*fc) * n ) * fl32(1/fl32(Fs)) ) + fl32(phase_offset)
+    (complex64 / real goes through NumPy's Smith division = multiply by the float32
+    reciprocal)."""
+    x = np.asarray(x)
+    if np.ndim(phase_offset) != 0:
+        # array phase promotes to complex128 (main.py:137,146) -- front-end only
+        nn = np.arange(x.shape[0], dtype=np.complex64)
+        return x * np.exp(1j * 2 * np.pi * fc * nn / Fs + 1j * phase_offset)
+    n = np.arange(x.shape[0], dtype=np.float32)
+    a = np.float32(2 * np.pi * fc)
+    rcp = np.float32(1.0) / np.float32(Fs)
+    ph = (a * n) * rcp
+    if phase_offset != 0:
+        ph = ph + np.float32(phase_offset)
+    rot = (np.cos(ph) + 1j * np.sin(ph)).astype(np.complex64)
+    return x * rot
+
+
+# --------------------------------------------------------------------------
+# Clutter filters (clutter_removal.py)
+# --------------------------------------------------------------------------
+
+def levinson_hermitian(c, b):
+    """Solve T w = b, T[i,j] = c[i-j] (i>=j), conj(c[j-i]) (i<j); complex128.
+
+    Restates scipy.linalg.solve_toeplitz(c, b) (clutter_removal.py:150: only the
+    first column is passed, so the first row is conj(c)).  Levinson-Durbin with
+    the backward predictor obtained from the forward one by conjugate reversal.
+    """
+    c = np.asarray(c, dtype=np.complex128)
+    b = np.asarray(b, dtype=np.complex128)
+    n = c.size
+    w = np.zeros(n, dtype=np.complex128)
+    # a: forward predictor polynomial, a[0]=1;  T_m a = [E_m, 0..0]^T
+    a = np.zeros(n, dtype=np.complex128)
+    a[0] = 1.0
+    err = c[0].real
+    w[0] = b[0] / c[0]
+    for m in range(1, n):
+        # reflection coefficient for order m
+        acc = np.dot(a[:m], c[m:0:-1])              # sum_i a[i] c[m-i]
+        k = -acc / err
+        prev = a[:m + 1].copy()
+        a[:m + 1] = prev + k * np.conj(prev[::-1])
+        err = err * (1.0 - (k * np.conj(k)).real)
+        # update the solution: residual of row m with current w
+        res = b[m] - np.dot(c[m:0:-1], w[:m])       # sum_j c[m-j] w[j]
+        g = res / err
+        w[:m + 1] += g * np.conj(a[m::-1])
+    return w
+
+
+def LS_Filter_Toeplitz(refChannel, srvChannel, filterLen, peek=10, return_filter=False):
+    """clutter_removal.py:109-160.  T = filterLen+peek taps; tap k <-> delay k-peek.
+
+    r = roll(ref, -peek) (:139, circular); c[k] = sum_{n>=k} r[n] conj(r[n-k]),
+    b[k] = sum_{n>=k} s[n] conj(r[n-k]) (:142-147); Hermitian-Toeplitz solve (:150);
+    out[n] = s[n] - sum_{k<=min(n,T-1)} w[k] r[n-k] (:153-155).  complex128 out.
+    """
+    ref = np.asarray(refChannel)
+    srv = np.asarray(srvChannel)
+    if ref.shape != srv.shape:                              # :133-135
+        raise ValueError("Input vectors must have the same length")
+    T = filterLen + peek
+    r = np.concatenate((ref[peek:], ref[:peek])) if peek else ref
+    c = xcorr(r, r, 0, T - 1)
+    b = xcorr(srv, r, 0, T - 1)
+    w = levinson_hermitian(c, b)
+    clutter = np.convolve(r.astype(np.complex128), w)[:srv.shape[0]]
+    out = srv.astype(np.complex128) - clutter
+    return (out, w) if return_filter else out
+
+
+def LS_Filter_Multiple(refChannel, srvChannel, filterLen, sampleRate, dopplerBins=(0,)):
+    """clutter_removal.py:162-187: chain LS_Filter_Toeplitz over Doppler bins, each on the
+    previous bin's output, reference frequency-shifted for non-zero bins (:184)."""
+    out = srvChannel
+    for fd in dopplerBins:
+        r = refChannel if fd == 0 else frequency_shift(refChannel, fd, sampleRate)
+        out = LS_Filter_Toeplitz(r, out, filterLen)
+    return out
+
+
+def LS_Filter(refChannel, srvChannel, filterLen, reg=1.0, peek=10, return_filter=False):
+    """clutter_removal.py:6-56 without materialising the N x T data matrix.
+
+    A[:,k] = roll(ref, k-peek) (:33-36) so (A^H A)[i,j] = g[i-j] with the *circular*
+    autocorrelation g[d] = sum_n ref[n] conj(ref[(n-d) mod N]) -- exactly Hermitian
+    Toeplitz -- and (A^H s)[k] = sum_n s[n] conj(ref[(n-k+peek) mod N]).  The
+    regularised system (:45) is solved here in complex128 (the reference uses
+    LAPACK in complex64); out = s - A w (:51) is a circular FIR.  complex64 out.
+    """
+    ref = np.asarray(refChannel)
+    srv = np.asarray(srvChannel)
+    if ref.shape != srv.shape:                              # :28-29
+        raise ValueError("Input vectors must have the same length")
+    N = ref.shape[0]
+    T = filterLen + peek
+    r128 = ref.astype(np.complex128)
+    s128 = srv.astype(np.complex128)
+    g = np.empty(T, dtype=np.complex128)
+    rhs = np.empty(T, dtype=np.complex128)
+    for d in range(T):
+        g[d] = np.vdot(np.roll(r128, d), r128)             # sum_n r[n] conj(r[n-d])
+        rhs[d] = np.vdot(np.roll(r128, d - peek), s128)    # sum_n s[n] conj(r[n-(d-peek)])
+    g[0] += reg
+    w = levinson_hermitian(g, rhs)
+    clutter = np.zeros(N, dtype=np.complex128)
+    for k in range(T):
+        clutter += w[k] * np.roll(r128, k - peek)
+    out = (s128 - clutter).astype(np.complex64)
+    return (out, w.astype(np.complex64)) if return_filter else out
+
+
+def NLMS_filter(refChannel, srvChannel, filterLen, mu, peek=10, initialTaps=None,
+                returnFilter=False):
+    """clutter_removal.py:189-249 (complex64 state, sample-recursive):
+        u_k[i] = ref[L+k+peek-i], i=0..T-1;  e = srv[k+L] - w^H u;  w += mu*u*conj(e)/(u^H u)
+        out[L+k] = e,  k = 0..N-T-1;  out is zero elsewhere.
+    Pure-Python loop: small cases only (oracle/c/nlms.c is the fast twin)."""
+    ref = np.asarray(refChannel)
+    srv = np.asarray(srvChannel)
+    if initialTaps is None:                                 # :218-225
+        w = np.zeros(filterLen + peek, dtype=np.complex64)
+    else:
+        w = np.asarray(initialTaps).copy()
+        filterLen = w.shape[0] - peek
+    T = filterLen + peek
+    N = srv.shape[0]
+    out = np.zeros(N, dtype=np.complex64)
+    mu32 = np.float32(mu)
+    for k in range(N - T):                                  # :234
+        u = ref[k + 1:k + T + 1][::-1]                      # :228,:237 sliding window, newest first
+        e = srv[k + filterLen] - np.vdot(w, u)              # :212
+        w = (w + mu32 * u * np.conj(e) / np.vdot(u, u)).astype(np.complex64)   # :213
+        out[filterLen + k] = e                              # :244
+    return (out, w) if returnFilter else out
+
+
+# --------------------------------------------------------------------------
+# Block pipeline semantics of main.py:169-194 (the harness row of SURVEY 8c)
+# --------------------------------------------------------------------------
+
+def overlap_frames(stream, chunk, depth):
+    """dask.array.overlap.overlap(x, depth, boundary=0) on 1-D chunks (main.py:178-181):
+    frame i = stream[i*chunk - depth : (i+1)*chunk + depth], zeros beyond the ends."""
+    stream = np.asarray(stream)
+    nchunks = stream.shape[0] // chunk
+    padded = np.concatenate((np.zeros(depth, stream.dtype), stream[:nchunks * chunk],
+                             np.zeros(depth, stream.dtype)))
+    return [padded[i * chunk:(i + 1) * chunk + 2 * depth] for i in range(nchunks)]
+
+
+def process_stream(ref, srv, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
+                   dopplerBins=(0, 1, -1, 2, -2), window=("kaiser", 5.0)):
+    """main.py:169-194 on an in-memory IF stream: per-chunk LS_Filter_Multiple (chunk =
+    cpi/2, :169-176), zero-boundary overlap of depth cpi/4 (:178-181), Kaiser window (:183),
+    fast_xambg per frame (:186-194), frames stacked on axis 2."""
+    from scipy.signal import get_window
+    C = cpi_samples // 2
+    depth = cpi_samples // 4
+    nchunks = ref.shape[0] // C
+    cleaned = np.concatenate([
+        LS_Filter_Multiple(ref[i * C:(i + 1) * C], srv[i * C:(i + 1) * C], num_range_cells,
+                           IF_sample_rate, list(dopplerBins)) for i in range(nchunks)])
+    w = get_window(window, cpi_samples) if isinstance(window, (tuple, str)) else window
+    rf = overlap_frames(ref, C, depth)
+    sf = overlap_frames(cleaned, C, depth)
+    frames = [fast_xambg(a, b, num_range_cells, num_doppler_cells, cpi_samples, w)
+              for a, b in zip(rf, sf)]
+    return np.concatenate(frames, axis=2)

@@ -1,0 +1,171 @@
+"""ctypes binding of libprcore.so (include/prcore.h) -- the only way the package computes.
+
+There is no CPU fallback: if the shared library is missing or no MI355X is visible the
+functions raise.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C passiveradar_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprcore.so")
+
+PRC_OK, PRC_EINVAL, PRC_ESHAPE, PRC_EHIP, PRC_EROCFFT, PRC_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+CAF_AUTO, CAF_DIRECT, CAF_FFT = 0, 1, 2
+DOPPLER_AUTO, DOPPLER_ROCFFT, DOPPLER_FUSED = 0, 1, 2
+
+
+class PrcoreError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libprcore error {code}: {msg}")
+        self.code = code
+
+
+class CafDesc(C.Structure):
+    _fields_ = [("n", C.c_int64), ("range_bins", C.c_int32), ("freq_bins", C.c_int32),
+                ("max_frames", C.c_int32), ("method", C.c_int32), ("doppler", C.c_int32),
+                ("ntaps", C.c_int32), ("taps_host", C.POINTER(C.c_float))]
+
+
+class LsDesc(C.Structure):
+    _fields_ = [("n", C.c_int64), ("filter_len", C.c_int32), ("peek", C.c_int32),
+                ("circular", C.c_int32), ("max_blocks", C.c_int32), ("method", C.c_int32)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_SIGNATURES = {
+    "prc_version": (C.c_int, []),
+    "prc_last_error": (C.c_char_p, []),
+    "prc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "prc_set_device": (C.c_int, [C.c_int]),
+    "prc_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "prc_free": (C.c_int, [C.c_void_p]),
+    "prc_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "prc_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "prc_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "prc_stream_sync": (C.c_int, [C.c_void_p]),
+    "prc_caf_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(CafDesc)]),
+    "prc_caf_plan_destroy": (C.c_int, [C.c_void_p]),
+    "prc_caf_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int64)]),
+    "prc_caf_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "prc_caf_execute_segments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                           C.c_void_p, C.c_int32, C.c_void_p]),
+    "prc_caf_execute_doppler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "prc_ls_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(LsDesc)]),
+    "prc_ls_plan_destroy": (C.c_int, [C.c_void_p]),
+    "prc_ls_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                 C.c_int32, C.c_double, C.POINTER(C.c_double), C.c_int32, C.c_double,
+                                 C.c_void_p, C.c_void_p]),
+    "prc_nlms_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                   C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
+                                   C.c_void_p]),
+    "prc_xcorr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                            C.c_void_p]),
+    "prc_frequency_shift": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                      C.c_double, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load libprcore.so once; raise (never fall back) if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} is not built: run `make -C passiveradar_amd/csrc` (hipcc, gfx950). "
+                    "passiveradar_amd has no CPU fallback.")
+            handle = C.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGNATURES.items():
+                fn = getattr(handle, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = handle
+    return _lib
+
+
+def check(rc):
+    """Map a prc_status to the reference's error convention (PRC_ESHAPE -> ValueError)."""
+    if rc == PRC_OK:
+        return
+    msg = lib().prc_last_error().decode("utf-8", "replace")
+    if rc == PRC_ESHAPE:
+        raise ValueError(msg)
+    if rc == PRC_EINVAL:
+        raise ValueError(msg)
+    if rc == PRC_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise PrcoreError(rc, msg)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().prc_device_count(C.byref(n))
+    return n.value if rc == PRC_OK else 0
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise PrcoreError(PRC_EHIP, "no ROCm device visible: " +
+                          lib().prc_last_error().decode("utf-8", "replace"))
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed region owned by Python (library-side allocator, no torch needed)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().prc_malloc(C.byref(p), max(self.nbytes, 8)))
+        self.ptr = p.value
+
+    def upload(self, arr, offset_bytes=0, stream=None):
+        arr = np.ascontiguousarray(arr)
+        assert offset_bytes + arr.nbytes <= self.nbytes
+        check(lib().prc_memcpy_h2d(self.ptr + offset_bytes, arr.ctypes.data, arr.nbytes, stream))
+        check(lib().prc_stream_sync(stream))   # arr may be a temporary
+
+    def zero(self, offset_bytes=0, nbytes=None, stream=None):
+        nbytes = self.nbytes - offset_bytes if nbytes is None else nbytes
+        check(lib().prc_memset(self.ptr + offset_bytes, 0, nbytes, stream))
+
+    def download(self, shape, dtype, offset_bytes=0, stream=None):
+        out = np.empty(shape, dtype=dtype)
+        assert offset_bytes + out.nbytes <= self.nbytes
+        check(lib().prc_memcpy_d2h(out.ctypes.data, self.ptr + offset_bytes, out.nbytes, stream))
+        check(lib().prc_stream_sync(stream))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().prc_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def is_device_tensor(x):
+    """torch CUDA/HIP tensor (zero-copy path) vs host array (staged through DeviceBuffer)."""
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+def torch_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,41 @@
+// Internal interfaces between the CAF translation units.
+#pragma once
+#include "common.h"
+
+// Slow-time buffer layouts written by the segment kernels and read by the Doppler stage.
+enum { PRC_Y_JK = 0,   // y[frame][j][k]   (k contiguous)  -> fused Doppler kernel
+       PRC_Y_KJ = 1 }; // y[frame][k][j]   (j contiguous)  -> rocFFT batched plan
+
+struct CafSegArgs {
+    const float2* ref;
+    const float2* srv;
+    const float* window;   // float32[n] or nullptr
+    const float* taps;     // float32[ntaps] or nullptr (boxcar)
+    float2* y;             // slow-time buffer
+    int64_t frame_stride;  // elements between consecutive frames in ref/srv
+    int64_t n;             // CPI length (circular-wrap modulus)
+    int64_t n_valid;       // samples >= n_valid read as zero
+    int64_t q;             // decimation
+    int32_t ntaps;         // FIR length (q+1 for the boxcar)
+    int32_t half;          // (ntaps-1)/2
+    int32_t range_bins;
+    int32_t freq_bins;
+    int32_t y_layout;
+};
+
+__device__ __forceinline__ void caf_store_y(const CafSegArgs& a, int frame, int64_t j, int k,
+                                            float2 v) {
+    const int64_t cols = a.range_bins + 1;
+    const int64_t base = (int64_t)frame * a.freq_bins * cols;
+    if (a.y_layout == PRC_Y_JK)
+        a.y[base + j * cols + k] = v;
+    else
+        a.y[base + (int64_t)k * a.freq_bins + j] = v;
+}
+
+int caf_launch_direct(const CafSegArgs& a, int nframes, hipStream_t stream);
+int caf_launch_fft(const CafSegArgs& a, int nframes, hipStream_t stream);
+bool caf_fft_supported(int64_t n, int range_bins, int freq_bins, int ntaps_is_boxcar);
+int caf_launch_doppler_fused(const float2* y, float2* out, int freq_bins, int range_bins,
+                             int nframes, hipStream_t stream);
+bool caf_doppler_fused_supported(int freq_bins);

@@ -1,0 +1,97 @@
+// Shared host/device helpers for libprcore (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <mutex>
+#include "../../include/prcore.h"
+
+#define PRC_WAVE 64
+
+void prc_set_error(const char* fmt, ...);
+
+#define PRC_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            prc_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                          __LINE__);                                                       \
+            return PRC_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+#define PRC_LAUNCH_CHECK()                                                                 \
+    do {                                                                                   \
+        hipError_t e__ = hipGetLastError();                                                \
+        if (e__ != hipSuccess) {                                                           \
+            prc_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__),      \
+                          __FILE__, __LINE__);                                             \
+            return PRC_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+#define PRC_REQUIRE(cond, code, ...)                                                       \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            prc_set_error(__VA_ARGS__);                                                    \
+            return (code);                                                                 \
+        }                                                                                  \
+    } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device-side complex helpers (float2 = complex64, double2 = complex128) ----
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// acc += p * conj(s)
+__device__ __forceinline__ void cmac_conj(float2& acc, float2 p, float2 s) {
+    acc.x = fmaf(p.x, s.x, acc.x);
+    acc.x = fmaf(p.y, s.y, acc.x);
+    acc.y = fmaf(p.y, s.x, acc.y);
+    acc.y = fmaf(-p.x, s.y, acc.y);
+}
+// acc += a * b
+__device__ __forceinline__ void cmac(float2& acc, float2 a, float2 b) {
+    acc.x = fmaf(a.x, b.x, acc.x);
+    acc.x = fmaf(-a.y, b.y, acc.x);
+    acc.y = fmaf(a.x, b.y, acc.y);
+    acc.y = fmaf(a.y, b.x, acc.y);
+}
+__device__ __forceinline__ double2 zmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 zconj(double2 a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ double2 zadd(double2 a, double2 b) {
+    return make_double2(a.x + b.x, a.y + b.y);
+}
+__device__ __forceinline__ double2 zsub(double2 a, double2 b) {
+    return make_double2(a.x - b.x, a.y - b.y);
+}
+__device__ __forceinline__ double2 zscale(double2 a, double s) {
+    return make_double2(a.x * s, a.y * s);
+}
+// a / b (b != 0), plain formula in double
+__device__ __forceinline__ double2 zdiv(double2 a, double2 b) {
+    double d = b.x * b.x + b.y * b.y;
+    return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+
+// The reference's frequency_shift keeps the sample index in complex64, so the phase ramp is
+// float32:  ph = fl32(fl32(a32 * n) * rcp32)  (signal_utils.py:24-27; NumPy complex/real
+// division multiplies by the float32 reciprocal).  No FMA contraction is possible here
+// (two multiplies), and the file is built without fast-math.
+struct PhaseRamp {
+    float a32;    // fl32(2*pi*fc)
+    float rcp32;  // fl32(1 / fl32(Fs))
+    float off32;  // fl32(phase_offset)
+    int enabled;  // 0: no rotation (fc == 0 and offset == 0)
+};
+__device__ __forceinline__ float2 phase_rot(const PhaseRamp& pr, int64_t n) {
+    float ph = (pr.a32 * (float)n) * pr.rcp32;
+    ph = ph + pr.off32;
+    float s, c;
+    sincosf(ph, &s, &c);
+    return make_float2(c, s);
+}

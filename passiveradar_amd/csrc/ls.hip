@@ -1,0 +1,518 @@
+// Block least-squares clutter cancellers (time-domain kernels).
+//
+// Replaces clutter_removal.py: LS_Filter_Toeplitz (:109-160), LS_Filter_Multiple (:162-187),
+// LS_Filter (:6-56) and the helpers they call, signal_utils.xcorr (:29-32) and
+// frequency_shift (:24-27).  Three kernels per Doppler bin:
+//   1. corr_partial_kernel : per-tile lag products   sum_m r[m] conj(r[m+k]),  sum_m r[m] conj(s[m+k])
+//      (scipy.signal.correlate 'valid' at :142-147), r = peek-rotated, phase-rotated reference
+//      generated on the fly while staging LDS (the reference materialises roll() and
+//      frequency_shift() arrays);
+//   2. levinson_kernel     : fp64 reduction of the partials + Hermitian-Toeplitz Levinson solve
+//      (scipy.linalg.solve_toeplitz at :150, complex128);
+//   3. fir_subtract_kernel : out = s - conv(r, w)[0:N] (np.convolve at :153-155), complex64.
+// With circular=1 the same kernels wrap indices modulo N, which is LS_Filter's circulant data
+// matrix: A^H A is exactly the circular-autocorrelation Toeplitz matrix, so no N x T matrix and
+// no dense GEMM is ever formed.
+#include "common.h"
+#include <vector>
+
+#define LSC_TILE 1024
+#define LSC_TILES_PER_BLOCK 4
+#define LSC_BLK (LSC_TILE * LSC_TILES_PER_BLOCK)
+#define LS_THREADS 256
+
+struct CorrArgs {
+    const float2* p_src;    // P source (reference for LS)
+    const float2* s1_src;   // first S source
+    const float2* s2_src;   // second S source (DUAL) or nullptr
+    int64_t p_stride, s1_stride, s2_stride;  // elements between batch items
+    int64_t n;
+    int32_t nlags;          // lags 0..nlags-1
+    int32_t peek_p, peek_s1, peek_s2;  // logical index m reads src[(m + peek) mod n]
+    int32_t rot_p, rot_s1, rot_s2;     // apply the phase ramp (on the source index) or not
+    int32_t circular;       // S index wraps modulo n, else zero beyond n
+    PhaseRamp pr;
+    float2* partial;        // [batch][nblk][nS][nlags]
+    int32_t nblk;
+};
+
+__device__ __forceinline__ float2 load_rot(const float2* __restrict__ src, int64_t m, int64_t n,
+                                           int peek, int rot, const PhaseRamp& pr) {
+    int64_t idx = m + peek;
+    if (idx >= n) idx -= n;
+    float2 v = src[idx];
+    if (rot) v = cmul(v, phase_rot(pr, idx));
+    return v;
+}
+
+template <int NLG, bool DUAL>
+__global__ __launch_bounds__(LS_THREADS) void corr_partial_kernel(CorrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* P = reinterpret_cast<float2*>(smem_raw);
+    float2* S1 = P + LSC_TILE;
+    float2* S2 = S1 + LSC_TILE + 64 * NLG;
+    float2* red = DUAL ? S2 + LSC_TILE + 64 * NLG : S2;   // 4 waves * (DUAL?2:1) * NLG * 64
+
+    constexpr int NS = DUAL ? 2 : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = blockIdx.x, b = blockIdx.y;
+    const float2* __restrict__ psrc = a.p_src + (int64_t)b * a.p_stride;
+    const float2* __restrict__ s1src = a.s1_src + (int64_t)b * a.s1_stride;
+    const float2* __restrict__ s2src = DUAL ? a.s2_src + (int64_t)b * a.s2_stride : nullptr;
+    const int64_t m_begin = (int64_t)blk * LSC_BLK;
+    int64_t m_end = m_begin + LSC_BLK;
+    if (m_end > a.n) m_end = a.n;
+
+    for (int L0 = 0; L0 < a.nlags; L0 += 64 * NLG) {
+        float2 acc[NS][NLG];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int g = 0; g < NLG; ++g) acc[s][g] = make_float2(0.f, 0.f);
+
+        for (int64_t t0 = m_begin; t0 < m_end; t0 += LSC_TILE) {
+            const int64_t rem = m_end - t0;
+            const int cnt = rem < LSC_TILE ? (int)rem : LSC_TILE;
+            for (int i = tid; i < LSC_TILE; i += LS_THREADS) {
+                float2 v = make_float2(0.f, 0.f);
+                if (i < cnt) v = load_rot(psrc, t0 + i, a.n, a.peek_p, a.rot_p, a.pr);
+                P[i] = v;
+            }
+            for (int i = tid; i < LSC_TILE + 64 * NLG; i += LS_THREADS) {
+                int64_t m = t0 + i + L0;
+                bool ok = true;
+                if (m >= a.n) {
+                    if (a.circular) m %= a.n; else ok = false;
+                }
+                float2 v1 = make_float2(0.f, 0.f), v2 = make_float2(0.f, 0.f);
+                if (ok) {
+                    v1 = load_rot(s1src, m, a.n, a.peek_s1, a.rot_s1, a.pr);
+                    if (DUAL) v2 = load_rot(s2src, m, a.n, a.peek_s2, a.rot_s2, a.pr);
+                }
+                S1[i] = v1;
+                if (DUAL) S2[i] = v2;
+            }
+            __syncthreads();
+            const int i0 = wave * (LSC_TILE / 4);
+            int i1 = i0 + LSC_TILE / 4;
+            if (i1 > cnt) i1 = cnt;
+            const float2* S1l = S1 + lane;
+            const float2* S2l = S2 + lane;
+#pragma unroll 2
+            for (int i = i0; i < i1; ++i) {
+                const float2 p = P[i];
+#pragma unroll
+                for (int g = 0; g < NLG; ++g) {
+                    cmac_conj(acc[0][g], p, S1l[i + 64 * g]);
+                    if (DUAL) cmac_conj(acc[NS - 1][g], p, S2l[i + 64 * g]);
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int g = 0; g < NLG; ++g) red[((wave * NS + s) * NLG + g) * 64 + lane] = acc[s][g];
+        __syncthreads();
+        for (int t = tid; t < NS * NLG * 64; t += LS_THREADS) {
+            float2 v = red[t];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float2 u = red[w * NS * NLG * 64 + t];
+                v.x += u.x;
+                v.y += u.y;
+            }
+            const int s = t / (NLG * 64);
+            const int lag = L0 + (t - s * NLG * 64);
+            if (lag < a.nlags)
+                a.partial[(((int64_t)b * a.nblk + blk) * NS + s) * a.nlags + lag] = v;
+        }
+        __syncthreads();
+    }
+}
+
+static int launch_corr(const CorrArgs& a, bool dual, int nbatch, hipStream_t stream) {
+    int nlg = (a.nlags + 63) / 64;
+    if (nlg > 8) nlg = 8;
+    dim3 grid((unsigned)a.nblk, (unsigned)nbatch);
+#define PRC_CORR_CASE(G)                                                                          \
+    case G: {                                                                                     \
+        if (dual) {                                                                               \
+            size_t lds = sizeof(float2) * (LSC_TILE + 2 * (LSC_TILE + 64 * G) + 4 * 2 * G * 64); \
+            hipLaunchKernelGGL((corr_partial_kernel<G, true>), grid, dim3(LS_THREADS), lds, stream, a); \
+        } else {                                                                                  \
+            size_t lds = sizeof(float2) * (LSC_TILE + (LSC_TILE + 64 * G) + 4 * G * 64);         \
+            hipLaunchKernelGGL((corr_partial_kernel<G, false>), grid, dim3(LS_THREADS), lds, stream, a); \
+        }                                                                                         \
+    } break;
+    switch (nlg) {
+        PRC_CORR_CASE(1)
+        PRC_CORR_CASE(2)
+        PRC_CORR_CASE(3)
+        PRC_CORR_CASE(4)
+        PRC_CORR_CASE(5)
+        PRC_CORR_CASE(6)
+        PRC_CORR_CASE(7)
+        PRC_CORR_CASE(8)
+    }
+#undef PRC_CORR_CASE
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}
+
+// ---- Levinson (fp64) ------------------------------------------------------------------
+// LDS: c[T], bb[T], a0[T], a1[T], w[T] (double2) + 8 double2 of reduction scratch.
+__device__ __forceinline__ double2 wave_sum_z(double2 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v.x += __shfl_down(v.x, off, 64);
+        v.y += __shfl_down(v.y, off, 64);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(LS_THREADS) void levinson_kernel(const float2* __restrict__ partial,
+                                                              int nblk, int T, double reg,
+                                                              double2* __restrict__ taps_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2* c = reinterpret_cast<double2*>(smem_raw);
+    double2* bb = c + T;
+    double2* abuf0 = bb + T;
+    double2* abuf1 = abuf0 + T;
+    double2* w = abuf1 + T;
+    double2* red = w + T;  // [2][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float2* part = partial + (int64_t)b * nblk * 2 * T;
+
+    // c[k] = conj(sum_blk partial_rr[k]),  bb[k] = conj(sum_blk partial_rs[k])   (fp64 sums)
+    for (int k = tid; k < T; k += LS_THREADS) {
+        double cr = 0, ci = 0, br = 0, bi = 0;
+        for (int blk = 0; blk < nblk; ++blk) {
+            const float2 u = part[((int64_t)blk * 2 + 0) * T + k];
+            const float2 v = part[((int64_t)blk * 2 + 1) * T + k];
+            cr += (double)u.x; ci += (double)u.y;
+            br += (double)v.x; bi += (double)v.y;
+        }
+        if (k == 0) cr += reg;
+        c[k] = make_double2(cr, -ci);
+        bb[k] = make_double2(br, -bi);
+        abuf0[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
+        abuf1[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
+        w[k] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    double err = c[0].x;
+    if (tid == 0) w[0] = zdiv(bb[0], c[0]);
+    __syncthreads();
+
+    double2* a_old = abuf0;
+    double2* a_new = abuf1;
+    for (int m = 1; m < T; ++m) {
+        double2 acc = make_double2(0, 0), dot = make_double2(0, 0);
+        for (int i = tid; i < m; i += LS_THREADS) {
+            const double2 cm = c[m - i];
+            acc = zadd(acc, zmul(a_old[i], cm));
+            dot = zadd(dot, zmul(cm, w[i]));
+        }
+        acc = wave_sum_z(acc);
+        dot = wave_sum_z(dot);
+        if (lane == 0) {
+            red[wave] = acc;
+            red[4 + wave] = dot;
+        }
+        __syncthreads();
+        acc = zadd(zadd(red[0], red[1]), zadd(red[2], red[3]));
+        dot = zadd(zadd(red[4], red[5]), zadd(red[6], red[7]));
+        const double2 k = make_double2(-acc.x / err, -acc.y / err);
+        err = err * (1.0 - (k.x * k.x + k.y * k.y));
+        const double2 res = zsub(bb[m], dot);
+        const double2 g = make_double2(res.x / err, res.y / err);
+        // a_new[j] = a_old[j] + k conj(a_old[m-j]);  w[j] += g conj(a_new[m-j]),
+        // with a_new[m-j] = a_old[m-j] + k conj(a_old[j])  (a_old[m] == 0)
+        for (int j = tid; j <= m; j += LS_THREADS) {
+            const double2 aj = a_old[j];
+            const double2 amj = a_old[m - j];
+            a_new[j] = zadd(aj, zmul(k, zconj(amj)));
+            const double2 anew_mj = zadd(amj, zmul(k, zconj(aj)));
+            w[j] = zadd(w[j], zmul(g, zconj(anew_mj)));
+        }
+        __syncthreads();
+        double2* t = a_old;
+        a_old = a_new;
+        a_new = t;
+    }
+    for (int k = tid; k < T; k += LS_THREADS) taps_out[(int64_t)b * T + k] = w[k];
+}
+
+// ---- FIR apply: out[n] = s[n] - sum_k w[k] r[n-k] ----------------------------------------
+#define FIR_OPT 4
+#define FIR_SPAN (LS_THREADS * FIR_OPT)
+
+struct FirArgs {
+    const float2* ref;
+    const float2* srv;
+    float2* out;
+    const double2* taps;   // [batch][T] complex128
+    int64_t ref_stride, srv_stride, out_stride;
+    int64_t n;
+    int32_t T, peek, circular, rot;
+    PhaseRamp pr;
+};
+
+__global__ __launch_bounds__(LS_THREADS) void fir_subtract_kernel(FirArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* W = reinterpret_cast<float2*>(smem_raw);   // T
+    float2* Rt = W + a.T;                                // FIR_SPAN + T - 1
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int64_t n0 = (int64_t)blockIdx.x * FIR_SPAN;
+    const float2* __restrict__ ref = a.ref + (int64_t)b * a.ref_stride;
+    const float2* __restrict__ srv = a.srv + (int64_t)b * a.srv_stride;
+    const double2* __restrict__ taps = a.taps + (int64_t)b * a.T;
+    for (int k = tid; k < a.T; k += LS_THREADS) {
+        const double2 t = taps[k];
+        W[k] = make_float2((float)t.x, (float)t.y);
+    }
+    const int halo = a.T - 1;
+    for (int i = tid; i < FIR_SPAN + halo; i += LS_THREADS) {
+        int64_t m = n0 - halo + i;
+        float2 v = make_float2(0.f, 0.f);
+        bool ok = m < a.n;
+        if (m < 0) {
+            if (a.circular) { m %= a.n; if (m < 0) m += a.n; } else ok = false;
+        }
+        if (ok) v = load_rot(ref, m, a.n, a.peek, a.rot, a.pr);
+        Rt[i] = v;
+    }
+    __syncthreads();
+    float2 acc[FIR_OPT];
+#pragma unroll
+    for (int o = 0; o < FIR_OPT; ++o) acc[o] = make_float2(0.f, 0.f);
+    const float2* Rl = Rt + tid + halo;
+#pragma unroll 2
+    for (int k = 0; k < a.T; ++k) {
+        const float2 wk = W[k];
+#pragma unroll
+        for (int o = 0; o < FIR_OPT; ++o) cmac(acc[o], wk, Rl[o * LS_THREADS - k]);
+    }
+#pragma unroll
+    for (int o = 0; o < FIR_OPT; ++o) {
+        const int64_t n = n0 + tid + o * LS_THREADS;
+        if (n < a.n) {
+            const float2 s = srv[n];
+            a.out[(int64_t)b * a.out_stride + n] = make_float2(s.x - acc[o].x, s.y - acc[o].y);
+        }
+    }
+}
+
+// ---- plan -------------------------------------------------------------------------------
+struct prc_ls_plan {
+    prc_ls_desc desc;
+    int T;
+    int nblk;
+    float2* d_partial = nullptr;
+    double2* d_taps = nullptr;
+    float2* d_tmp[2] = {nullptr, nullptr};
+    std::mutex mtx;
+};
+
+extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
+    if (!p) return PRC_OK;
+    if (p->d_partial) (void)hipFree(p->d_partial);
+    if (p->d_taps) (void)hipFree(p->d_taps);
+    if (p->d_tmp[0]) (void)hipFree(p->d_tmp[0]);
+    if (p->d_tmp[1]) (void)hipFree(p->d_tmp[1]);
+    delete p;
+    return PRC_OK;
+}
+
+static size_t levinson_lds(int T) { return sizeof(double2) * ((size_t)5 * T + 8); }
+static size_t fir_lds(int T) { return sizeof(float2) * ((size_t)T + FIR_SPAN + T - 1); }
+
+extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
+    PRC_REQUIRE(plan && d, PRC_EINVAL, "prc_ls_plan_create: null argument");
+    PRC_REQUIRE(d->n > 0 && d->filter_len > 0 && d->peek >= 0 && d->max_blocks > 0, PRC_EINVAL,
+                "prc_ls_plan_create: non-positive size");
+    const int T = d->filter_len + d->peek;
+    PRC_REQUIRE(T < d->n, PRC_EINVAL, "prc_ls_plan_create: filter_len+peek (%d) >= n (%lld)", T,
+                (long long)d->n);
+    PRC_REQUIRE(levinson_lds(T) <= 160 * 1024, PRC_EUNSUPPORTED,
+                "prc_ls_plan_create: %d taps exceed the LDS-resident Levinson solver (max 2047)", T);
+    prc_ls_plan* p = new prc_ls_plan();
+    p->desc = *d;
+    p->T = T;
+    p->nblk = (int)ceil_div64(d->n, LSC_BLK);
+    hipError_t e = hipMalloc(&p->d_partial, sizeof(float2) * (size_t)d->max_blocks * p->nblk * 2 * T);
+    if (e == hipSuccess) e = hipMalloc(&p->d_taps, sizeof(double2) * (size_t)d->max_blocks * T);
+    if (e == hipSuccess) e = hipMalloc(&p->d_tmp[0], sizeof(float2) * (size_t)d->max_blocks * d->n);
+    if (e == hipSuccess) e = hipMalloc(&p->d_tmp[1], sizeof(float2) * (size_t)d->max_blocks * d->n);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)levinson_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)fir_subtract_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+        prc_set_error("prc_ls_plan_create: device setup failed: %s", hipGetErrorString(e));
+        prc_ls_plan_destroy(p);
+        return PRC_EHIP;
+    }
+    *plan = p;
+    return PRC_OK;
+}
+
+static PhaseRamp make_ramp(double fc, double fs, double phase_offset) {
+    PhaseRamp pr;
+    pr.a32 = (float)(2.0 * 3.14159265358979323846 * fc);
+    pr.rcp32 = 1.0f / (float)fs;
+    pr.off32 = (float)phase_offset;
+    pr.enabled = (fc != 0.0 || phase_offset != 0.0) ? 1 : 0;
+    return pr;
+}
+
+extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, int64_t stride,
+                              void* out, int64_t out_stride, int32_t nblocks, double sample_rate,
+                              const double* bins, int32_t nbins, double reg, void* taps_out,
+                              void* stream_) {
+    PRC_REQUIRE(p && ref && srv && out && bins, PRC_EINVAL, "prc_ls_execute: null argument");
+    PRC_REQUIRE(nblocks > 0 && nblocks <= p->desc.max_blocks, PRC_EINVAL,
+                "prc_ls_execute: nblocks=%d outside [1, %d]", nblocks, p->desc.max_blocks);
+    PRC_REQUIRE(nbins > 0, PRC_EINVAL, "prc_ls_execute: no Doppler bins");
+    PRC_REQUIRE(stride >= p->desc.n && out_stride >= p->desc.n, PRC_ESHAPE,
+                "prc_ls_execute: stride shorter than the block length");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::lock_guard<std::mutex> lk(p->mtx);
+    const int T = p->T;
+    const int64_t n = p->desc.n;
+    const float2* cur = (const float2*)srv;
+    int64_t cur_stride = stride;
+    for (int ib = 0; ib < nbins; ++ib) {
+        const PhaseRamp pr = make_ramp(bins[ib], sample_rate, 0.0);
+        float2* dst;
+        int64_t dst_stride;
+        if (ib == nbins - 1) {
+            dst = (float2*)out;
+            dst_stride = out_stride;
+        } else {
+            dst = p->d_tmp[ib & 1];
+            dst_stride = n;
+        }
+        CorrArgs ca;
+        ca.p_src = (const float2*)ref;  ca.p_stride = stride;
+        ca.s1_src = (const float2*)ref; ca.s1_stride = stride;
+        ca.s2_src = cur;                ca.s2_stride = cur_stride;
+        ca.n = n;
+        ca.nlags = T;
+        ca.peek_p = p->desc.peek;  ca.peek_s1 = p->desc.peek;  ca.peek_s2 = 0;
+        ca.rot_p = pr.enabled;     ca.rot_s1 = pr.enabled;     ca.rot_s2 = 0;
+        ca.circular = p->desc.circular;
+        ca.pr = pr;
+        ca.partial = p->d_partial;
+        ca.nblk = p->nblk;
+        int rc = launch_corr(ca, true, nblocks, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(levinson_kernel, dim3(nblocks), dim3(LS_THREADS), levinson_lds(T), stream,
+                           p->d_partial, p->nblk, T, reg, p->d_taps);
+        PRC_LAUNCH_CHECK();
+        FirArgs fa;
+        fa.ref = (const float2*)ref;  fa.ref_stride = stride;
+        fa.srv = cur;                 fa.srv_stride = cur_stride;
+        fa.out = dst;                 fa.out_stride = dst_stride;
+        fa.taps = p->d_taps;
+        fa.n = n;
+        fa.T = T;
+        fa.peek = p->desc.peek;
+        fa.circular = p->desc.circular;
+        fa.rot = pr.enabled;
+        fa.pr = pr;
+        dim3 grid((unsigned)ceil_div64(n, FIR_SPAN), (unsigned)nblocks);
+        hipLaunchKernelGGL(fir_subtract_kernel, grid, dim3(LS_THREADS), fir_lds(T), stream, fa);
+        PRC_LAUNCH_CHECK();
+        cur = dst;
+        cur_stride = dst_stride;
+    }
+    if (taps_out)
+        PRC_HIP(hipMemcpyAsync(taps_out, p->d_taps, sizeof(double2) * (size_t)nblocks * T,
+                               hipMemcpyDeviceToDevice, stream));
+    return PRC_OK;
+}
+
+// ---- xcorr (signal_utils.py:29-32) ---------------------------------------------------------
+__global__ void xcorr_reduce_kernel(const float2* __restrict__ partial, int nblk, int nlags,
+                                    float2* __restrict__ out, int out_base, int out_step,
+                                    int lag_begin, int conj_flag) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x + lag_begin;
+    if (k >= nlags) return;
+    double re = 0, im = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const float2 v = partial[(int64_t)blk * nlags + k];
+        re += (double)v.x;
+        im += (double)v.y;
+    }
+    out[out_base + out_step * k] = make_float2((float)re, (float)(conj_flag ? -im : im));
+}
+
+extern "C" int prc_xcorr(const void* s1, const void* s2, int64_t n, int32_t nlead, int32_t nlag,
+                         void* out, void* stream_) {
+    PRC_REQUIRE(s1 && s2 && out, PRC_EINVAL, "prc_xcorr: null argument");
+    PRC_REQUIRE(n > 0 && nlead >= 0 && nlag >= 0, PRC_EINVAL, "prc_xcorr: bad size");
+    PRC_REQUIRE(nlead < n && nlag < n, PRC_EINVAL, "prc_xcorr: lag span exceeds the signal");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nblk = (int)ceil_div64(n, LSC_BLK);
+    const int maxl = (nlag > nlead ? nlag : nlead) + 1;
+    float2* d_part = nullptr;
+    PRC_HIP(hipMalloc(&d_part, sizeof(float2) * (size_t)nblk * maxl));
+    int rc = PRC_OK;
+    // d = 0..nlag:  z[nlead+d] = conj( sum_m s2[m] conj(s1[m+d]) )
+    {
+        CorrArgs ca = {};
+        ca.p_src = (const float2*)s2;  ca.s1_src = (const float2*)s1;  ca.s2_src = nullptr;
+        ca.n = n;  ca.nlags = nlag + 1;  ca.partial = d_part;  ca.nblk = nblk;
+        rc = launch_corr(ca, false, 1, stream);
+        if (rc == PRC_OK) {
+            hipLaunchKernelGGL(xcorr_reduce_kernel, dim3((nlag + 1 + 63) / 64), dim3(64), 0, stream,
+                               d_part, nblk, nlag + 1, (float2*)out, nlead, 1, 0, 1);
+            if (hipGetLastError() != hipSuccess) rc = PRC_EHIP;
+        }
+    }
+    // e = 1..nlead: z[nlead-e] = sum_n s1[n] conj(s2[n+e])
+    if (rc == PRC_OK && nlead > 0) {
+        CorrArgs ca = {};
+        ca.p_src = (const float2*)s1;  ca.s1_src = (const float2*)s2;  ca.s2_src = nullptr;
+        ca.n = n;  ca.nlags = nlead + 1;  ca.partial = d_part;  ca.nblk = nblk;
+        rc = launch_corr(ca, false, 1, stream);
+        if (rc == PRC_OK) {
+            hipLaunchKernelGGL(xcorr_reduce_kernel, dim3((nlead + 63) / 64), dim3(64), 0, stream,
+                               d_part, nblk, nlead + 1, (float2*)out, nlead, -1, 1, 0);
+            if (hipGetLastError() != hipSuccess) rc = PRC_EHIP;
+        }
+    }
+    hipError_t e = hipStreamSynchronize(stream);
+    (void)hipFree(d_part);
+    if (rc != PRC_OK) { prc_set_error("prc_xcorr: kernel launch failed"); return rc; }
+    PRC_HIP(e);
+    return PRC_OK;
+}
+
+// ---- frequency_shift (signal_utils.py:24-27) ------------------------------------------------
+__global__ void freq_shift_kernel(const float2* __restrict__ x, float2* __restrict__ y, int64_t n,
+                                  PhaseRamp pr) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = cmul(x[i], phase_rot(pr, i));
+}
+
+extern "C" int prc_frequency_shift(const void* x, void* y, int64_t n, double fc, double fs,
+                                   double phase_offset, void* stream) {
+    PRC_REQUIRE(x && y, PRC_EINVAL, "prc_frequency_shift: null argument");
+    PRC_REQUIRE(n > 0 && fs != 0.0, PRC_EINVAL, "prc_frequency_shift: bad size or rate");
+    PhaseRamp pr = make_ramp(fc, fs, phase_offset);
+    pr.enabled = 1;
+    int64_t blocks = ceil_div64(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(freq_shift_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float2*)x, (float2*)y, n, pr);
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}

@@ -1,0 +1,168 @@
+"""Thin Python owners of the libprcore plans (device-pointer level).
+
+Everything here takes raw device pointers (ints) + a hipStream_t, so it works both for the
+NumPy-facing drop-in functions (which stage through ``_lib.DeviceBuffer``) and for callers that
+already hold torch device tensors (``tensor.data_ptr()``; bench.py, stream.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _ptr(x):
+    """int / c_void_p / DeviceBuffer / torch tensor -> c_void_p"""
+    if x is None:
+        return None
+    if isinstance(x, _lib.DeviceBuffer):
+        return C.c_void_p(x.ptr)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    if isinstance(x, C.c_void_p):
+        return x
+    return C.c_void_p(int(x))
+
+
+class CafPlan:
+    """prc_caf_plan: fast_xambg for up to ``max_frames`` frames per launch."""
+
+    def __init__(self, n, range_bins, freq_bins, max_frames=1, method=_lib.CAF_AUTO,
+                 doppler=_lib.DOPPLER_AUTO, taps=None):
+        self.n, self.range_bins, self.freq_bins = int(n), int(range_bins), int(freq_bins)
+        self.max_frames = int(max_frames)
+        d = _lib.CafDesc()
+        d.n, d.range_bins, d.freq_bins = self.n, self.range_bins, self.freq_bins
+        d.max_frames, d.method, d.doppler = self.max_frames, int(method), int(doppler)
+        self._taps = None
+        if taps is not None:
+            self._taps = np.ascontiguousarray(taps, dtype=np.float32)
+            d.ntaps = self._taps.size
+            d.taps_host = self._taps.ctypes.data_as(C.POINTER(C.c_float))
+        else:
+            d.ntaps = 0
+            d.taps_host = None
+        h = C.c_void_p()
+        check(lib().prc_caf_plan_create(C.byref(h), C.byref(d)))
+        self._h = h
+        m, dp, ws = C.c_int32(), C.c_int32(), C.c_int64()
+        check(lib().prc_caf_plan_info(self._h, C.byref(m), C.byref(dp), C.byref(ws)))
+        self.method, self.doppler, self.workspace_bytes = m.value, dp.value, ws.value
+
+    @property
+    def out_shape(self):
+        return (self.freq_bins, self.range_bins + 1)
+
+    def execute(self, ref, srv, out, nframes=1, frame_stride=None, n_valid=None, window=None,
+                stream=None):
+        check(lib().prc_caf_execute(self._h, _ptr(ref), _ptr(srv),
+                                    self.n if frame_stride is None else int(frame_stride),
+                                    self.n if n_valid is None else int(n_valid),
+                                    _ptr(window), _ptr(out), int(nframes), stream))
+
+    def execute_segments(self, ref, srv, nframes=1, frame_stride=None, n_valid=None, window=None,
+                         stream=None):
+        check(lib().prc_caf_execute_segments(self._h, _ptr(ref), _ptr(srv),
+                                             self.n if frame_stride is None else int(frame_stride),
+                                             self.n if n_valid is None else int(n_valid),
+                                             _ptr(window), int(nframes), stream))
+
+    def execute_doppler(self, out, nframes=1, stream=None):
+        check(lib().prc_caf_execute_doppler(self._h, _ptr(out), int(nframes), stream))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().prc_caf_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LsPlan:
+    """prc_ls_plan: LS_Filter_Toeplitz / LS_Filter_Multiple / LS_Filter on up to max_blocks blocks."""
+
+    def __init__(self, n, filter_len, peek=10, circular=False, max_blocks=1, method=0):
+        self.n, self.filter_len, self.peek = int(n), int(filter_len), int(peek)
+        self.ntaps = self.filter_len + self.peek
+        self.max_blocks = int(max_blocks)
+        d = _lib.LsDesc()
+        d.n, d.filter_len, d.peek = self.n, self.filter_len, self.peek
+        d.circular, d.max_blocks, d.method = int(bool(circular)), self.max_blocks, int(method)
+        h = C.c_void_p()
+        check(lib().prc_ls_plan_create(C.byref(h), C.byref(d)))
+        self._h = h
+
+    def execute(self, ref, srv, out, nblocks=1, stride=None, out_stride=None, sample_rate=1.0,
+                doppler_bins=(0,), reg=0.0, taps_out=None, stream=None):
+        bins = (C.c_double * len(doppler_bins))(*[float(b) for b in doppler_bins])
+        check(lib().prc_ls_execute(self._h, _ptr(ref), _ptr(srv),
+                                   self.n if stride is None else int(stride), _ptr(out),
+                                   self.n if out_stride is None else int(out_stride), int(nblocks),
+                                   float(sample_rate), bins, len(doppler_bins), float(reg),
+                                   _ptr(taps_out), stream))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().prc_ls_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def nlms_execute(ref, srv, out, n, filter_len, mu, peek=10, taps_in=None, taps_out=None,
+                 nstreams=1, stride=None, out_stride=None, stream=None):
+    check(lib().prc_nlms_execute(_ptr(ref), _ptr(srv), int(n), int(n if stride is None else stride),
+                                 int(filter_len), int(peek), float(mu), _ptr(taps_in), _ptr(out),
+                                 int(n if out_stride is None else out_stride), _ptr(taps_out),
+                                 int(nstreams), stream))
+
+
+# ---- per-thread plan cache (dask-style concurrent callers each get their own plans) ------
+_tls = threading.local()
+
+
+def cached_plan(key, factory, limit=8):
+    cache = getattr(_tls, "plans", None)
+    if cache is None:
+        cache = _tls.plans = {}
+    plan = cache.get(key)
+    if plan is None:
+        if len(cache) >= limit:
+            old_key = next(iter(cache))
+            cache.pop(old_key).close()
+        plan = cache[key] = factory()
+    return plan
+
+
+class Staging:
+    """Per-thread grow-only device scratch for the NumPy-facing functions."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name, nbytes):
+        b = self.bufs.get(name)
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                b.free()
+            b = self.bufs[name] = _lib.DeviceBuffer(nbytes)
+        return b
+
+
+def staging():
+    st = getattr(_tls, "staging", None)
+    if st is None:
+        st = _tls.staging = Staging()
+    return st

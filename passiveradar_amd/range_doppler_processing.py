@@ -1,0 +1,90 @@
+"""Drop-in for the reference's ``passiveRadar/range_doppler_processing.py`` on MI355X.
+
+``fast_xambg`` keeps the reference signature, argument meaning, return shape/dtype and the
+ValueError on mismatched inputs (range_doppler_processing.py:12-90) and runs on the HIP kernels
+behind libprcore.so.  Inputs may be NumPy arrays (staged to the GPU and back) or torch device
+tensors (zero copy, result returned as a torch tensor on the same device).
+"""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+
+from . import _lib, engine
+
+__all__ = ["fast_xambg", "caf_plan_for"]
+
+
+@functools.lru_cache(maxsize=16)
+def _named_window(spec, n):
+    # range_doppler_processing.py:57-58 -- host side, computed once per (spec, length)
+    from scipy.signal import get_window
+    return np.ascontiguousarray(get_window(spec, n), dtype=np.float32)
+
+
+@functools.lru_cache(maxsize=4)
+def _long_taps(q):
+    # range_doppler_processing.py:76 -- flat-top FIR of 10q+1 taps (shortFilt=False)
+    from scipy.signal import firwin
+    return np.ascontiguousarray(firwin(10 * q + 1, 1.0 / q, window="flattop"), dtype=np.float32)
+
+
+def caf_plan_for(n, rangeBins, freqBins, shortFilt=True, max_frames=1, method=_lib.CAF_AUTO,
+                 doppler=_lib.DOPPLER_AUTO):
+    q = int(n / freqBins) if freqBins else 0
+    key = ("caf", n, rangeBins, freqBins, bool(shortFilt), max_frames, method, doppler)
+    taps = None if shortFilt else _long_taps(q)
+    return engine.cached_plan(key, lambda: engine.CafPlan(n, rangeBins, freqBins, max_frames,
+                                                          method, doppler, taps))
+
+
+def fast_xambg(refChannel, srvChannel, rangeBins, freqBins, inputLen=None, window=None,
+               shortFilt=True):
+    """Fast cross-ambiguity function (same contract as the reference, :12-90).
+
+    Returns an array of shape (freqBins, rangeBins+1, 1), complex64: column k is delay
+    rangeBins-k samples, rows are fftshift-ed Doppler bins.
+    """
+    if tuple(refChannel.shape) != tuple(srvChannel.shape):                  # :46-49
+        raise ValueError("Input vectors must have the same length")
+    n_in = int(refChannel.shape[0])
+    n = n_in if inputLen is None else int(inputLen)
+    if n_in > n:
+        raise ValueError("index can't contain negative values")              # np.pad at :53
+    if isinstance(window, (tuple, str)):
+        window = _named_window(window, n)
+    elif window is not None and not _lib.is_device_tensor(window):
+        window = np.ascontiguousarray(window, dtype=np.float32)
+        if window.shape[0] != n:
+            raise ValueError(f"operands could not be broadcast together with shapes ({n},) "
+                             f"({window.shape[0]},)")
+    plan = caf_plan_for(n, int(rangeBins), int(freqBins), shortFilt)
+
+    if _lib.is_device_tensor(refChannel):
+        import torch
+        ref = refChannel.to(torch.complex64).contiguous()
+        srv = srvChannel.to(torch.complex64).contiguous()
+        win = None
+        if window is not None:
+            win = window if _lib.is_device_tensor(window) else torch.from_numpy(window).to(ref.device)
+            win = win.to(torch.float32).contiguous()
+        out = torch.empty((int(freqBins), int(rangeBins) + 1, 1), dtype=torch.complex64,
+                          device=ref.device)
+        plan.execute(ref, srv, out, 1, n, n_in, win, stream=_lib.torch_stream_ptr())
+        return out
+
+    ref = np.ascontiguousarray(refChannel, dtype=np.complex64)
+    srv = np.ascontiguousarray(srvChannel, dtype=np.complex64)   # complex128 srv is narrowed
+    st = engine.staging()
+    d_ref = st.get("caf_ref", 8 * n_in)
+    d_srv = st.get("caf_srv", 8 * n_in)
+    d_out = st.get("caf_out", 8 * int(freqBins) * (int(rangeBins) + 1))
+    d_ref.upload(ref)
+    d_srv.upload(srv)
+    d_win = None
+    if window is not None:
+        d_win = st.get("caf_win", 4 * n)
+        d_win.upload(window)
+    plan.execute(d_ref, d_srv, d_out, 1, n, n_in, d_win)
+    return d_out.download((int(freqBins), int(rangeBins) + 1, 1), np.complex64)

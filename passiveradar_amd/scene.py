@@ -1,0 +1,80 @@
+"""Deterministic synthetic two-channel IQ scenes.
+
+The reference ships no data; tests, goldens and bench.py all draw their inputs
+from this generator so that the build container and the GPU box see identical
+arrays without shipping them.  Counter-based Philox stream keyed by the seed.
+
+    ref[n] : unit-variance complex white Gaussian, complex64
+    srv[n] = 1.0 ref[n-2] + 0.3 ref[n-9] + 0.1 ref[n-40]            (direct path + clutter, 0 Hz)
+             + sum_m A_m ref[n-d_m] exp(j 2 pi f_m n / Fs)          (moving targets)
+             + noise_amp * noise[n]
+Delays are circular shifts inside the generated block.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED_BASE = 20260926 * 1000
+
+DEFAULT_CLUTTER = ((2, 1.0), (9, 0.3), (40, 0.1))
+
+
+def default_targets(rangeBins):
+    """(delay samples, Doppler Hz, amplitude) triples of SURVEY 8d, clipped to the lag span."""
+    return ((min(60, max(rangeBins - 8, 1)), 80.0, 0.01),
+            (max(rangeBins // 2, 1), -35.0, 0.003),
+            (max(rangeBins - 5, 1), 120.0, 0.003))
+
+
+def scene_seed(cfg: int, channel: int = 0) -> int:
+    return SEED_BASE + cfg * 10 + channel
+
+
+def _cwhite(gen, n):
+    x = gen.standard_normal(2 * n, dtype=np.float32) * np.float32(np.sqrt(0.5))
+    return x.view(np.complex64)
+
+
+def white_reference(n, seed):
+    gen = np.random.Generator(np.random.Philox(key=seed))
+    return _cwhite(gen, n)
+
+
+def make_scene(n, sample_rate, rangeBins, seed, targets=None, clutter=DEFAULT_CLUTTER,
+               noise_amp=0.003, colour=None):
+    """Return (ref, srv) complex64 arrays of length n.
+
+    colour: optional short real FIR applied (circularly) to the white reference to
+    make a mildly coloured illuminator (used for the "mildly coloured" LS cases).
+    """
+    gen = np.random.Generator(np.random.Philox(key=seed))
+    ref = _cwhite(gen, n)
+    if colour is not None:
+        acc = np.zeros(n, dtype=np.complex128)
+        for i, c in enumerate(colour):
+            acc += c * np.roll(ref, i)
+        ref = (acc / np.sqrt(np.sum(np.square(colour)))).astype(np.complex64)
+    noise = _cwhite(gen, n)
+    if targets is None:
+        targets = default_targets(rangeBins)
+    acc = np.zeros(n, dtype=np.complex128)
+    for d, a in clutter:
+        acc += a * np.roll(ref, d)
+    t = np.arange(n, dtype=np.float64) / float(sample_rate)
+    for d, fd, a in targets:
+        acc += a * np.roll(ref, d) * np.exp(2j * np.pi * fd * t)
+    acc += noise_amp * noise
+    return ref, acc.astype(np.complex64)
+
+
+def make_stream(nchunks, chunk, sample_rate, rangeBins, seed, **kw):
+    """A contiguous IF stream of nchunks*chunk samples (one scene; delays wrap at the ends)."""
+    return make_scene(nchunks * chunk, sample_rate, rangeBins, seed, **kw)
+
+
+def expected_peak_cell(delay, doppler_hz, n, sample_rate, rangeBins, freqBins):
+    """(row, col) where fast_xambg puts an echo srv[n]=ref[n-delay] e^{+j2 pi fd n/Fs}:
+    range axis reversed, Doppler axis mirrored."""
+    cpi = n / float(sample_rate)
+    row = int(round(freqBins / 2 - doppler_hz * cpi)) % freqBins
+    return row, rangeBins - delay

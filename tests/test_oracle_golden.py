@@ -1,0 +1,143 @@
+"""The oracle (oracle/np_oracle.py) against every golden vector generated from the reference.
+CPU only.  This is what pins the oracle; the GPU parity tests then compare HIP vs oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CAF_SMALL, GOLDEN, golden_window, load_golden, rel_err
+from oracle import np_oracle as O
+from passiveradar_amd import scene
+
+
+@pytest.mark.parametrize("name", CAF_SMALL)
+def test_caf_small(name):
+    g = load_golden("caf_" + name)
+    out = O.fast_xambg(g["ref"], g["srv"], int(g["R"]), int(g["F"]), int(g["inputLen"]),
+                       golden_window(g), bool(g["shortFilt"]))
+    assert out.shape == g["out"].shape and out.dtype == np.complex64
+    assert rel_err(out, g["out"]) < 2e-6
+
+
+def test_caf_libcalls_form_matches():
+    g = load_golden("caf_oddq")
+    out = O.fast_xambg_libcalls(g["ref"], g["srv"], int(g["R"]), int(g["F"]), g["window"])
+    assert rel_err(out, g["out"]) < 1e-6
+
+
+def test_caf_cfg1_full_size():
+    g = load_golden("caf_cfg1")
+    from scipy.signal import get_window
+    n, R, F = int(g["N"]), int(g["R"]), int(g["F"])
+    ref, srv = scene.make_scene(n, float(g["fs"]), R, int(g["seed"]))
+    out = O.fast_xambg(ref, srv, R, F, n, get_window(("kaiser", 5.0), n))
+    assert rel_err(out, g["out"]) < 2e-6
+
+
+def test_caf_axis_conventions():
+    # echo srv[n] = ref[n-7] e^{+j 2 pi 5 n / Fs}, 1 s CPI -> row F/2-5, column R-7
+    n, R, F = 4096, 20, 64
+    ref = scene.white_reference(n, 11)
+    srv = (np.roll(ref, 7) * np.exp(2j * np.pi * 5 * np.arange(n) / n)).astype(np.complex64)
+    X = np.abs(O.fast_xambg(ref, srv, R, F, n, None)[:, :, 0])
+    assert np.unravel_index(X.argmax(), X.shape) == scene.expected_peak_cell(7, 5.0, n, n, R, F)
+    D = np.abs(O.direct_xambg(ref, srv, R, F, float(n))[:, :, 0])      # not mirrored
+    assert np.unravel_index(D.argmax(), D.shape) == (F // 2 + 5, R - 7)
+
+
+def test_caf_shape_error():
+    with pytest.raises(ValueError):
+        O.fast_xambg(np.zeros(8, np.complex64), np.zeros(9, np.complex64), 1, 2)
+
+
+def test_xcorr():
+    g = load_golden("xcorr")
+    for key, (nl, ng) in {"z_0_20": (0, 20), "z_7_0": (7, 0), "z_3_9": (3, 9)}.items():
+        z = O.xcorr(g["s1"], g["s2"], nl, ng)
+        assert z.dtype == np.complex64 and rel_err(z, g[key]) < 2e-6
+    assert rel_err(O.xcorr(g["s1"], g["s1"], 0, 15), g["z_auto"]) < 2e-6
+
+
+def test_frequency_shift():
+    g = load_golden("freqshift")
+    x, _ = scene.make_scene(int(g["n"]), float(g["fs"]), 8, int(g["seed"]))
+    assert np.array_equal(x[:64], g["x_head"])          # generator is deterministic
+    st = int(g["stride"])
+    fs = float(g["fs"])
+    for key, fc, ph in (("y_p1", 1, 0), ("y_m2", -2, 0), ("y_f", 37.5, 0), ("y_ph", 80.0, 0.3)):
+        y = O.frequency_shift(x, fc, fs, ph)
+        assert y.dtype == np.complex64
+        assert np.abs(y[::st] - g[key]).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["ls_toeplitz_white", "ls_toeplitz_peek0", "ls_toeplitz_coloured"])
+def test_ls_toeplitz(name):
+    g = load_golden(name)
+    out, taps = O.LS_Filter_Toeplitz(g["ref"], g["srv"], int(g["L"]), int(g["peek"]), True)
+    assert out.dtype == np.complex128 and taps.dtype == np.complex128
+    assert rel_err(taps, g["taps"]) < 5e-6
+    assert rel_err(out, g["out"]) < 5e-6
+
+
+def test_levinson_against_scipy():
+    from scipy.linalg import solve_toeplitz
+    rng = np.random.default_rng(5)
+    c = rng.standard_normal(40) + 1j * rng.standard_normal(40)
+    c[0] = 12.0
+    b = rng.standard_normal(40) + 1j * rng.standard_normal(40)
+    assert rel_err(O.levinson_hermitian(c, b), solve_toeplitz(c, b)) < 1e-12
+
+
+def test_ls_multiple():
+    g = load_golden("ls_multiple")
+    out = O.LS_Filter_Multiple(g["ref"], g["srv"], int(g["L"]), float(g["fs"]), list(g["bins"]))
+    assert rel_err(out, g["out"]) < 5e-6
+
+
+@pytest.mark.parametrize("name", ["ls_direct", "ls_direct_reg"])
+def test_ls_direct(name):
+    g = load_golden(name)
+    out, taps = O.LS_Filter(g["ref"], g["srv"], int(g["L"]), float(g["reg"]), int(g["peek"]), True)
+    assert out.dtype == np.complex64
+    assert rel_err(taps, g["taps"]) < 2e-5          # the reference solves in complex64 (LAPACK)
+    assert rel_err(out, g["out"]) < 5e-5
+
+
+def test_nlms():
+    g = load_golden("nlms")
+    out, taps = O.NLMS_filter(g["ref"], g["srv"], int(g["L"]), float(g["mu"]), int(g["peek"]), None, True)
+    assert rel_err(out, g["out"]) < 1e-5 and rel_err(taps, g["taps"]) < 1e-5
+    gw = load_golden("nlms_warm")
+    out, taps = O.NLMS_filter(gw["ref"], gw["srv"], 999, float(gw["mu"]), 10, gw["initialTaps"], True)
+    assert rel_err(out, gw["out"]) < 1e-5 and rel_err(taps, gw["taps"]) < 1e-5
+    g7 = load_golden("nlms_t74")
+    out, taps = O.NLMS_filter(g7["ref"], g7["srv"], int(g7["L"]), float(g7["mu"]), int(g7["peek"]), None, True)
+    assert rel_err(out, g7["out"]) < 1e-5 and rel_err(taps, g7["taps"]) < 1e-5
+    # support of the output (:231): zero before L and from n-peek on
+    L, pk = int(g["L"]), int(g["peek"])
+    assert not out[:0].any() and not g["out"][:L].any() and not g["out"][-pk:].any()
+
+
+def test_stream_pipeline():
+    g = load_golden("stream")
+    C, R, F = int(g["C"]), int(g["R"]), int(g["F"])
+    out = O.process_stream(g["ref"], g["srv"], 2 * C, R, F, float(g["fs"]))
+    assert out.shape == g["out"].shape == (F, R + 1, 6)
+    assert rel_err(out, g["out"]) < 1e-5
+
+
+def test_c_twin_nlms_and_caf():
+    from oracle import c_oracle
+    g = load_golden("nlms")
+    out, taps = c_oracle.nlms(g["ref"], g["srv"], int(g["L"]), float(g["mu"]), int(g["peek"]))
+    assert rel_err(out, g["out"]) < 1e-5 and rel_err(taps, g["taps"]) < 1e-5
+    gw = load_golden("nlms_warm")
+    out, taps = c_oracle.nlms(gw["ref"], gw["srv"], 999, float(gw["mu"]), 10, gw["initialTaps"])
+    assert rel_err(out, gw["out"]) < 1e-5 and rel_err(taps, gw["taps"]) < 1e-5
+    for name in ("p2", "oddq", "nondiv", "lags_gt_q", "bigq"):
+        g = load_golden("caf_" + name)
+        w = golden_window(g)
+        X = c_oracle.fast_xambg(g["ref"], g["srv"], int(g["R"]), int(g["F"]),
+                                None if w is None else w)
+        assert rel_err(X, g["out"]) < 2e-6, name
