@@ -132,6 +132,13 @@ int prc_ls_execute(prc_ls_plan* plan, const void* ref, const void* srv, int64_t 
                    const double* doppler_bins_host, int32_t nbins, double reg,
                    void* taps_out, void* stream);
 
+/* Per-kernel timing for bench.py's roofline: when enabled, HIP events are recorded on the
+ * caller's stream around every kernel of the next prc_ls_execute.  prc_ls_get_profile waits
+ * for them and returns ms[0..2] = correlation / Levinson / FIR kernel time of that execute
+ * (summed over its Doppler bins) and the number of launches of each kind. */
+int prc_ls_set_profiling(prc_ls_plan* plan, int32_t enable);
+int prc_ls_get_profile(prc_ls_plan* plan, double* ms, int32_t* launches_per_kind);
+
 /* ---- NLMS_filter (clutter_removal.py:189-249) ---------------------------------------- */
 /* nstreams independent sample-recursive filters, one wavefront each.  taps_in: optional
  * complex64 [nstreams][T] initial taps (initialTaps), NULL = zeros.  taps_out: optional

@@ -279,6 +279,26 @@ def LS_Filter_Multiple(refChannel, srvChannel, filterLen, sampleRate, dopplerBin
     return out
 
 
+def LS_Filter_Multiple_libcalls(ref, srv, filterLen, sampleRate, dopplerBins=(0,), peek=10):
+    """Same result as LS_Filter_Multiple, but issuing the library calls the reference issues
+    (scipy correlate 'valid' on zero-padded reference, scipy solve_toeplitz, np.convolve,
+    complex64 phase ramp) -- the honest CPU cost of clutter_removal.py:162-187 for bench.py."""
+    from scipy.linalg import solve_toeplitz
+    from scipy.signal import correlate
+    T = filterLen + peek
+    cur = srv
+    idx = np.arange(ref.shape[0], dtype=np.complex64)
+    for fd in dopplerBins:
+        shifted = ref if fd == 0 else ref * np.exp(1j * 2 * np.pi * fd * idx / sampleRate)
+        r = np.roll(shifted, -peek)
+        rp = np.pad(r, (T - 1, 0))
+        col = correlate(r, rp, mode="valid")
+        rhs = correlate(cur, rp, mode="valid")
+        taps = solve_toeplitz(col, rhs)
+        cur = cur - np.convolve(r, taps)[:cur.shape[0]]
+    return cur
+
+
 def LS_Filter(refChannel, srvChannel, filterLen, reg=1.0, peek=10, return_filter=False):
     """clutter_removal.py:6-56 without materialising the N x T data matrix.
 

@@ -65,6 +65,8 @@ _SIGNATURES = {
     "prc_ls_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                  C.c_int32, C.c_double, C.POINTER(C.c_double), C.c_int32, C.c_double,
                                  C.c_void_p, C.c_void_p]),
+    "prc_ls_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "prc_ls_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "prc_nlms_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                    C.c_void_p]),

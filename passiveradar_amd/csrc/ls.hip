@@ -314,6 +314,10 @@ struct prc_ls_plan {
     float2* d_partial = nullptr;
     double2* d_taps = nullptr;
     float2* d_tmp[2] = {nullptr, nullptr};
+    // optional per-kernel timing (bench.py roofline): events around every launch of one execute
+    int profiling = 0;
+    std::vector<hipEvent_t> ev;     // 4 per Doppler bin: before corr, after corr, after levinson, after fir
+    int ev_bins = 0;
     std::mutex mtx;
 };
 
@@ -323,6 +327,7 @@ extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_tmp[0]) (void)hipFree(p->d_tmp[0]);
     if (p->d_tmp[1]) (void)hipFree(p->d_tmp[1]);
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
     return PRC_OK;
 }
@@ -387,6 +392,14 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
     const int64_t n = p->desc.n;
     const float2* cur = (const float2*)srv;
     int64_t cur_stride = stride;
+    if (p->profiling) {
+        while ((int)p->ev.size() < 4 * nbins) {
+            hipEvent_t e;
+            PRC_HIP(hipEventCreate(&e));
+            p->ev.push_back(e);
+        }
+        p->ev_bins = nbins;
+    }
     for (int ib = 0; ib < nbins; ++ib) {
         const PhaseRamp pr = make_ramp(bins[ib], sample_rate, 0.0);
         float2* dst;
@@ -410,11 +423,14 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
         ca.pr = pr;
         ca.partial = p->d_partial;
         ca.nblk = p->nblk;
+        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 0], stream));
         int rc = launch_corr(ca, true, nblocks, stream);
         if (rc) return rc;
+        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 1], stream));
         hipLaunchKernelGGL(levinson_kernel, dim3(nblocks), dim3(LS_THREADS), levinson_lds(T), stream,
                            p->d_partial, p->nblk, T, reg, p->d_taps);
         PRC_LAUNCH_CHECK();
+        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
         FirArgs fa;
         fa.ref = (const float2*)ref;  fa.ref_stride = stride;
         fa.srv = cur;                 fa.srv_stride = cur_stride;
@@ -429,12 +445,40 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
         dim3 grid((unsigned)ceil_div64(n, FIR_SPAN), (unsigned)nblocks);
         hipLaunchKernelGGL(fir_subtract_kernel, grid, dim3(LS_THREADS), fir_lds(T), stream, fa);
         PRC_LAUNCH_CHECK();
+        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 3], stream));
         cur = dst;
         cur_stride = dst_stride;
     }
     if (taps_out)
         PRC_HIP(hipMemcpyAsync(taps_out, p->d_taps, sizeof(double2) * (size_t)nblocks * T,
                                hipMemcpyDeviceToDevice, stream));
+    return PRC_OK;
+}
+
+extern "C" int prc_ls_set_profiling(prc_ls_plan* p, int32_t enable) {
+    PRC_REQUIRE(p, PRC_EINVAL, "prc_ls_set_profiling: null plan");
+    std::lock_guard<std::mutex> lk(p->mtx);
+    p->profiling = enable ? 1 : 0;
+    p->ev_bins = 0;
+    return PRC_OK;
+}
+
+// ms[0..2] = total milliseconds of the correlation / Levinson / FIR kernels of the LAST execute
+// (summed over its Doppler bins); synchronises on the recorded events.
+extern "C" int prc_ls_get_profile(prc_ls_plan* p, double* ms, int32_t* launches_per_kind) {
+    PRC_REQUIRE(p && ms, PRC_EINVAL, "prc_ls_get_profile: null argument");
+    std::lock_guard<std::mutex> lk(p->mtx);
+    PRC_REQUIRE(p->profiling && p->ev_bins > 0, PRC_EINVAL, "prc_ls_get_profile: nothing recorded");
+    ms[0] = ms[1] = ms[2] = 0.0;
+    for (int ib = 0; ib < p->ev_bins; ++ib) {
+        PRC_HIP(hipEventSynchronize(p->ev[4 * ib + 3]));
+        for (int k = 0; k < 3; ++k) {
+            float t = 0.f;
+            PRC_HIP(hipEventElapsedTime(&t, p->ev[4 * ib + k], p->ev[4 * ib + k + 1]));
+            ms[k] += t;
+        }
+    }
+    if (launches_per_kind) *launches_per_kind = p->ev_bins;
     return PRC_OK;
 }
 

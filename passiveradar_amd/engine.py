@@ -109,6 +109,16 @@ class LsPlan:
                                    float(sample_rate), bins, len(doppler_bins), float(reg),
                                    _ptr(taps_out), stream))
 
+    def set_profiling(self, enable=True):
+        check(lib().prc_ls_set_profiling(self._h, int(bool(enable))))
+
+    def get_profile(self):
+        """(ms_corr, ms_levinson, ms_fir, launches_per_kind) of the last execute"""
+        ms = (C.c_double * 3)()
+        k = C.c_int32()
+        check(lib().prc_ls_get_profile(self._h, ms, C.byref(k)))
+        return ms[0], ms[1], ms[2], k.value
+
     def close(self):
         if getattr(self, "_h", None):
             lib().prc_ls_plan_destroy(self._h)

@@ -1,0 +1,204 @@
+"""Block pipeline of the reference's main.py:169-194, batched on one GPU and sharded over GPUs.
+
+What a frame is: the IF stream is cut into chunks of C = cpi_samples/2
+(config.py:71); the LS canceller runs per chunk, independently (main.py:169-176); frame i is the
+CAF over stream[i*C - C/2 : i*C + 3C/2] of (ref, cleaned srv) with zeros beyond the stream ends
+(da.overlap.overlap(depth=cpi/4, boundary=0), main.py:178-181), Kaiser(5.0) window (main.py:183).
+nframes == nchunks, frames stacked on the last axis of the saved array (main.py:200-224).
+
+Device layout: ref and cleaned-srv live in HBM as ONE zero-padded stream each,
+[C/2 zeros | chunk 0 | chunk 1 | ... | C/2 zeros]; the LS kernels write chunk c straight into the
+cleaned stream and the CAF kernels read frame i at element offset i*C with frame stride C, so the
+50 % overlap costs no copy.  Frames shard contiguously over ranks; each rank re-filters the one
+extra chunk each side its first/last frame touches (LS taps are per chunk, so there is no halo
+exchange) and the only collective is the final gather of the (F, R+1) maps (RCCL via
+torch.distributed; gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+__all__ = ["Shard", "plan_shard", "gather_frames", "HipBackend", "StreamProcessor"]
+
+
+@dataclass(frozen=True)
+class Shard:
+    rank: int
+    world: int
+    nchunks: int       # chunks (== frames) in the whole stream
+    frame_lo: int      # frames [frame_lo, frame_hi) belong to this rank
+    frame_hi: int
+    chunk_lo: int      # chunks [chunk_lo, chunk_hi) must be resident + LS-filtered on this rank
+    chunk_hi: int
+
+    @property
+    def nframes(self):
+        return self.frame_hi - self.frame_lo
+
+    @property
+    def nlocal_chunks(self):
+        return self.chunk_hi - self.chunk_lo
+
+    def frame_offset(self, i, C):
+        """element offset of global frame i inside the local zero-padded stream
+        [C/2 zeros | chunks chunk_lo..chunk_hi | C/2 zeros]"""
+        return (i - self.chunk_lo) * C
+
+
+def plan_shard(nchunks, rank=0, world=1):
+    """Contiguous frame ranges of ceil(nchunks/world); frame i touches chunks i-1..i+1."""
+    per = -(-nchunks // world)
+    lo = min(rank * per, nchunks)
+    hi = min(lo + per, nchunks)
+    if hi <= lo:
+        return Shard(rank, world, nchunks, lo, lo, lo, lo)
+    return Shard(rank, world, nchunks, lo, hi, max(lo - 1, 0), min(hi + 1, nchunks))
+
+
+def gather_frames(local, shard, group=None, dst=0):
+    """Gather per-rank frame blocks [m_r][F][R+1] (torch tensors, complex64) to rank ``dst``.
+    Returns the full [nchunks][F][R+1] tensor on dst, None elsewhere.  Single collective."""
+    import torch
+    import torch.distributed as dist
+    if shard.world == 1:
+        return local
+    per = -(-shard.nchunks // shard.world)
+    F, cols = local.shape[1], local.shape[2]
+    # complex tensors go over the wire as float pairs (RCCL has no complex dtype)
+    send = torch.zeros((per, F, cols, 2), dtype=torch.float32, device=local.device)
+    if shard.nframes:
+        send[:shard.nframes] = torch.view_as_real(local)
+    if dist.get_rank(group) == dst:
+        recv = [torch.empty_like(send) for _ in range(shard.world)]
+        dist.gather(send, recv, dst=dst, group=group)
+        full = torch.view_as_complex(torch.cat(recv, dim=0).contiguous())
+        return full[:shard.nchunks]
+    dist.gather(send, None, dst=dst, group=group)
+    return None
+
+
+class HipBackend:
+    """The compute of one shard on one MI355X: batched LS chunks + batched overlapped CAF frames."""
+
+    def __init__(self, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
+                 doppler_bins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), clutter="ls",
+                 batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02):
+        import torch
+        from . import engine
+        from .range_doppler_processing import _named_window
+        self.torch = torch
+        self.engine = engine
+        self.cpi = int(cpi_samples)
+        self.C = self.cpi // 2
+        self.R, self.F = int(num_range_cells), int(num_doppler_cells)
+        self.fs = float(IF_sample_rate)
+        self.bins = tuple(float(b) for b in doppler_bins)
+        self.clutter = clutter
+        self.batch = int(batch)
+        self.nlms_mu = float(nlms_mu)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        with torch.cuda.device(self.device):
+            self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch, caf_method, doppler_method)
+            self.ls = None
+            if clutter == "ls":
+                self.ls = engine.LsPlan(self.C, self.R, 10, False, self.batch)
+            if isinstance(window, (tuple, str)):
+                w = _named_window(window, self.cpi)
+            else:
+                w = None if window is None else np.ascontiguousarray(window, dtype=np.float32)
+            self.window = None if w is None else torch.from_numpy(w).to(self.device)
+
+    def _stream(self):
+        from . import _lib
+        return _lib.torch_stream_ptr()
+
+    def padded(self, chunks):
+        """[C/2 zeros | chunks | C/2 zeros] complex64 on the device (chunks: 1-D host or device)."""
+        torch = self.torch
+        t = chunks if torch.is_tensor(chunks) else torch.from_numpy(np.ascontiguousarray(chunks, dtype=np.complex64))
+        n = t.shape[0]
+        buf = torch.zeros(n + self.C, dtype=torch.complex64, device=self.device)
+        buf[self.C // 2:self.C // 2 + n].copy_(t, non_blocking=True)
+        return buf
+
+    def clean(self, ref_pad, srv_pad, nlocal):
+        """LS_Filter_Multiple / NLMS per chunk, chunk c of the padded stream -> same place in the
+        returned padded cleaned stream (main.py:169-176)."""
+        torch = self.torch
+        C, h = self.C, self.C // 2
+        if self.clutter is None:
+            return srv_pad
+        out = torch.zeros_like(srv_pad)
+        with torch.cuda.device(self.device):
+            for c0 in range(0, nlocal, self.batch):
+                nb = min(self.batch, nlocal - c0)
+                off = h + c0 * C
+                if self.clutter == "ls":
+                    self.ls.execute(ref_pad[off:], srv_pad[off:], out[off:], nb, C, C, self.fs,
+                                    self.bins, 0.0, None, self._stream())
+                else:
+                    self.engine.nlms_execute(ref_pad[off:], srv_pad[off:], out[off:], C, self.R,
+                                             self.nlms_mu, 10, None, None, nb, C, C, self._stream())
+        return out
+
+    def frames(self, ref_pad, clean_pad, offsets_first, nframes):
+        """fast_xambg on nframes overlapped frames starting at element offset offsets_first (stride C)."""
+        torch = self.torch
+        out = torch.empty((nframes, self.F, self.R + 1), dtype=torch.complex64, device=self.device)
+        with torch.cuda.device(self.device):
+            for f0 in range(0, nframes, self.batch):
+                nb = min(self.batch, nframes - f0)
+                off = offsets_first + f0 * self.C
+                self.caf.execute(ref_pad[off:], clean_pad[off:], out[f0:], nb, self.C, self.cpi,
+                                 self.window, self._stream())
+        return out
+
+
+class StreamProcessor:
+    """main.py:169-194 for an in-memory IF stream; ``backend`` does the per-shard compute."""
+
+    def __init__(self, backend, rank=0, world=1, group=None):
+        self.backend = backend
+        self.rank, self.world, self.group = rank, world, group
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        """config: the dict of passiveradar_amd.config.getConfiguration (reference keys)."""
+        be = HipBackend(config["cpi_samples"], config["num_range_cells"], config["num_doppler_cells"],
+                        config["IF_sample_rate"], **kw)
+        return cls(be)
+
+    def process_local(self, ref, srv):
+        """ref, srv: the whole stream (host arrays or device tensors).  Returns (frames [m][F][R+1]
+        for this rank's shard, shard)."""
+        C = self.backend.C
+        nchunks = int(ref.shape[0]) // C
+        sh = plan_shard(nchunks, self.rank, self.world)
+        if sh.nframes == 0:
+            return self.backend.frames_empty() if hasattr(self.backend, "frames_empty") else None, sh
+        lo, hi = sh.chunk_lo * C, sh.chunk_hi * C
+        ref_pad = self.backend.padded(ref[lo:hi])
+        srv_pad = self.backend.padded(srv[lo:hi])
+        clean_pad = self.backend.clean(ref_pad, srv_pad, sh.nlocal_chunks)
+        frames = self.backend.frames(ref_pad, clean_pad, sh.frame_offset(sh.frame_lo, C), sh.nframes)
+        return frames, sh
+
+    def process(self, ref, srv, gather=True):
+        """Returns [nframes][F][R+1] (rank 0 when sharded; None on other ranks if gather)."""
+        frames, sh = self.process_local(ref, srv)
+        if self.world == 1 or not gather:
+            return frames
+        if frames is None:
+            import torch
+            frames = torch.zeros((0, self.backend.F, self.backend.R + 1), dtype=torch.complex64,
+                                 device=getattr(self.backend, "device", "cpu"))
+        return gather_frames(frames, sh, self.group)
+
+    @staticmethod
+    def to_reference_layout(frames):
+        """[nframes][F][R+1] -> the reference's saved array (F, R+1, nframes) (main.py:200-224)."""
+        if hasattr(frames, "permute"):
+            return frames.permute(1, 2, 0)
+        return np.moveaxis(np.asarray(frames), 0, 2)

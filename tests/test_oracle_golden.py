@@ -141,3 +141,9 @@ def test_c_twin_nlms_and_caf():
         X = c_oracle.fast_xambg(g["ref"], g["srv"], int(g["R"]), int(g["F"]),
                                 None if w is None else w)
         assert rel_err(X, g["out"]) < 2e-6, name
+
+
+def test_ls_libcalls_form_matches():
+    g = load_golden("ls_multiple")
+    out = O.LS_Filter_Multiple_libcalls(g["ref"], g["srv"], int(g["L"]), float(g["fs"]), list(g["bins"]))
+    assert rel_err(out, g["out"]) < 1e-7
