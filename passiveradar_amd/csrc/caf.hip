@@ -22,6 +22,7 @@ struct prc_caf_plan {
     int half;
     float* d_taps = nullptr;         // device copy of the long decimation FIR (or null)
     float2* d_y = nullptr;           // slow-time buffer, max_frames * F * (R+1)
+    float2* d_y2 = nullptr;          // [j][k]-ordered staging written by the FFT segment kernel
     size_t y_bytes = 0;
     rocfft_plan fft = nullptr;       // one batched plan for max_frames
     int fft_frames = 0;
@@ -122,6 +123,12 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
                       hipGetErrorString(hipGetLastError()));
         return fail(PRC_EHIP);
     }
+    if (p->method == PRC_CAF_FFT && p->doppler == PRC_DOPPLER_ROCFFT) {
+        if (hipMalloc(&p->d_y2, p->y_bytes) != hipSuccess) {
+            prc_set_error("prc_caf_plan_create: hipMalloc(%zu) failed", p->y_bytes);
+            return fail(PRC_EHIP);
+        }
+    }
     if (!boxcar) {
         if (hipMalloc(&p->d_taps, sizeof(float) * d->ntaps) != hipSuccess ||
             hipMemcpy(p->d_taps, d->taps_host, sizeof(float) * d->ntaps, hipMemcpyHostToDevice) != hipSuccess) {
@@ -144,6 +151,7 @@ extern "C" int prc_caf_plan_destroy(prc_caf_plan* p) {
     if (p->d_work) (void)hipFree(p->d_work);
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_y) (void)hipFree(p->d_y);
+    if (p->d_y2) (void)hipFree(p->d_y2);
     delete p;
     return PRC_OK;
 }
@@ -153,7 +161,7 @@ extern "C" int prc_caf_plan_info(const prc_caf_plan* p, int32_t* method, int32_t
     PRC_REQUIRE(p, PRC_EINVAL, "prc_caf_plan_info: null plan");
     if (method) *method = p->method;
     if (doppler) *doppler = p->doppler;
-    if (workspace_bytes) *workspace_bytes = (int64_t)(p->y_bytes + p->work_bytes);
+    if (workspace_bytes) *workspace_bytes = (int64_t)(p->y_bytes * (p->d_y2 ? 2 : 1) + p->work_bytes);
     return PRC_OK;
 }
 
@@ -185,7 +193,15 @@ static int run_segments(prc_caf_plan* p, const void* ref, const void* srv, int64
     a.range_bins = p->desc.range_bins;
     a.freq_bins = p->desc.freq_bins;
     a.y_layout = p->doppler == PRC_DOPPLER_FUSED ? PRC_Y_JK : PRC_Y_KJ;
-    if (p->method == PRC_CAF_FFT) return caf_launch_fft(a, nframes, stream);
+    if (p->method == PRC_CAF_FFT) {
+        // the FFT kernel writes whole rows y[j][0..R] (coalesced); rocFFT wants j contiguous
+        if (p->doppler == PRC_DOPPLER_FUSED) return caf_launch_fft(a, nframes, stream);
+        a.y = p->d_y2;
+        a.y_layout = PRC_Y_JK;
+        int rc = caf_launch_fft(a, nframes, stream);
+        if (rc) return rc;
+        return caf_launch_transpose_jk_kj(p->d_y2, p->d_y, a.freq_bins, a.range_bins + 1, nframes, stream);
+    }
     return caf_launch_direct(a, nframes, stream);
 }
 

@@ -1,12 +1,182 @@
-// FFT-domain segment correlation + fused Doppler FFT (filled in after the direct path is green).
+// FFT-domain cross-ambiguity segment sums: the HBM-bound form of fast_xambg's hot loop.
+//
+// Replaces range_doppler_processing.py:81-86 (roll * ref * window -> boxcar decimate) for the
+// boxcar decimator (:72).  For slow-time sample j the (q+1)-sample segment is cut into pieces of
+// B = 1024 - R samples; for each piece
+//     U = FFT_1024( w*ref[piece], zero padded ),  V = FFT_1024( srv[piece .. piece+B+R) ),
+//     Wacc += conj(U) V                                   (registers, permuted frequency layout)
+// and ONE inverse FFT per segment returns all R+1 lags:  y[j, R-l] = conj( IFFT(Wacc)[l] ).
+// One wavefront owns one segment end to end (fft_wave.h: 16 points per lane, private LDS tile,
+// no workgroup barrier in the loop); ref, srv and the window are each read once with
+// coalesced 512-byte wave loads (srv pieces overlap by R samples, served by L2), so the kernel
+// moves ~20 N bytes per frame against ~0.4 GFLOP of butterflies: HBM-bound, not VALU-bound
+// (the time-domain form in caf_direct.hip is 4.9 GFLOP per frame at config 2).
 #include "caf_internal.h"
+#include "fft_wave.h"
+#include <math.h>
 
-bool caf_fft_supported(int64_t, int, int, int) { return false; }
-bool caf_doppler_fused_supported(int) { return false; }
-int caf_launch_fft(const CafSegArgs&, int, hipStream_t) {
-    prc_set_error("FFT segment method not built");
-    return PRC_EUNSUPPORTED;
+void fftw_make_tables(float2* t) {
+    const double PI = 3.14159265358979323846;
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int n2 = 0; n2 < 64; ++n2) {
+            const double a = -2.0 * PI * (double)(k1 * n2) / 1024.0;
+            t[k1 * 64 + n2] = make_float2((float)cos(a), (float)sin(a));
+        }
+    for (int m = 0; m < 16; ++m)
+        for (int j = 0; j < 4; ++j) {
+            const double a = -2.0 * PI * (double)(m * j) / 64.0;
+            t[FFTW_TW1 + 4 * m + j] = make_float2((float)cos(a), (float)sin(a));
+        }
 }
+
+static float2* g_dev_tab[16] = {nullptr};
+static std::mutex g_tab_mtx;
+
+// Device copy of the twiddle tables for the current device (created once per device).
+int fftw_device_tables(const float2** out) {
+    int dev = 0;
+    PRC_HIP(hipGetDevice(&dev));
+    PRC_REQUIRE(dev >= 0 && dev < 16, PRC_EINVAL, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_tab_mtx);
+    if (!g_dev_tab[dev]) {
+        float2 host[FFTW_TABLE];
+        fftw_make_tables(host);
+        float2* d = nullptr;
+        PRC_HIP(hipMalloc(&d, sizeof(host)));
+        PRC_HIP(hipMemcpy(d, host, sizeof(host), hipMemcpyHostToDevice));
+        g_dev_tab[dev] = d;
+    }
+    *out = g_dev_tab[dev];
+    return PRC_OK;
+}
+
+#define CAFF_WAVES 4
+
+struct CafFftArgs {
+    CafSegArgs s;
+    const float2* tab;
+    int32_t piece;     // B = 1024 - range_bins
+};
+
+__global__ __launch_bounds__(64 * CAFF_WAVES) void caf_fft_kernel(CafFftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* tab = reinterpret_cast<float2*>(smem_raw);
+    float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
+    fft_load_tables(tab, a.tab);
+    __syncthreads();
+
+    const FftLane f = fft_lane_setup();
+    const int lane = f.lane;
+    const int64_t j = (int64_t)blockIdx.x * CAFF_WAVES + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (j >= a.s.freq_bins) return;
+    const float2* __restrict__ ref = a.s.ref + (int64_t)b * a.s.frame_stride;
+    const float2* __restrict__ srv = a.s.srv + (int64_t)b * a.s.frame_stride;
+    const float* __restrict__ win = a.s.window;
+    const int64_t N = a.s.n, NV = a.s.n_valid;
+    const int R = a.s.range_bins;
+    const int B = a.piece;
+
+    const int64_t n_hi = j * a.s.q + a.s.half;
+    const int64_t n_lo = n_hi - (a.s.ntaps - 1);
+    const int64_t lo = n_lo < 0 ? 0 : n_lo;
+    const int64_t hi = n_hi > N - 1 ? N - 1 : n_hi;
+
+    float2 acc[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc[m] = make_float2(0.f, 0.f);
+
+    for (int64_t n0 = lo; n0 <= hi; n0 += B) {
+        const int64_t rem = hi - n0 + 1;
+        const int cnt = rem < B ? (int)rem : B;
+        float2 u[16], v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = 64 * r + lane;
+            const int64_t n = n0 + idx;
+            float2 x = make_float2(0.f, 0.f);
+            if (idx < cnt && n < NV) {
+                x = ref[n];
+                if (win) {
+                    const float g = win[n];
+                    x.x *= g;
+                    x.y *= g;
+                }
+            }
+            u[r] = x;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = 64 * r + lane;
+            int64_t n = n0 + idx;
+            if (n >= N) n %= N;                  // circular wrap of srv inside the frame (:82)
+            float2 x = make_float2(0.f, 0.f);
+            if (idx < cnt + R && n < NV) x = srv[n];
+            v[r] = x;
+        }
+        fft1024_fwd(u, tile, tab, f);
+        fft1024_fwd(v, tile, tab, f);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) cmac_conj_a(acc[m], u[m], v[m]);
+    }
+    fft1024_inv(acc, tile, tab, f);
+    const float sc = 1.0f / 1024.0f;
+    float2* __restrict__ yrow = a.s.y + ((int64_t)b * a.s.freq_bins + j) * (R + 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lag = 64 * r + lane;
+        if (lag <= R) yrow[R - lag] = make_float2(acc[r].x * sc, -acc[r].y * sc);
+    }
+}
+
+// y_jk[b][j][k] -> y_kj[b][k][j]
+__global__ __launch_bounds__(256) void transpose_jk_kj_kernel(const float2* __restrict__ src,
+                                                              float2* __restrict__ dst, int F,
+                                                              int cols) {
+    __shared__ float2 t[32][33];
+    const int b = blockIdx.z;
+    const int64_t base = (int64_t)b * F * cols;
+    const int j0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r, k = k0 + tx;
+        if (j < F && k < cols) t[r][tx] = src[base + (int64_t)j * cols + k];
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, j = j0 + tx;
+        if (k < cols && j < F) dst[base + (int64_t)k * F + j] = t[tx][r];
+    }
+}
+
+bool caf_fft_supported(int64_t n, int range_bins, int freq_bins, int boxcar) {
+    (void)n;
+    (void)freq_bins;
+    return boxcar && range_bins >= 1 && range_bins <= 768;
+}
+
+int caf_launch_fft(const CafSegArgs& s, int nframes, hipStream_t stream) {
+    CafFftArgs a;
+    a.s = s;
+    a.piece = FFTW_P - s.range_bins;
+    int rc = fftw_device_tables(&a.tab);
+    if (rc) return rc;
+    dim3 grid((unsigned)((s.freq_bins + CAFF_WAVES - 1) / CAFF_WAVES), (unsigned)nframes);
+    const size_t lds = sizeof(float2) * (FFTW_TABLE + CAFF_WAVES * FFTW_TILE);
+    hipLaunchKernelGGL(caf_fft_kernel, grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}
+
+int caf_launch_transpose_jk_kj(const float2* src, float2* dst, int freq_bins, int cols, int nframes,
+                               hipStream_t stream) {
+    dim3 grid((freq_bins + 31) / 32, (cols + 31) / 32, nframes);
+    hipLaunchKernelGGL(transpose_jk_kj_kernel, grid, dim3(256), 0, stream, src, dst, freq_bins, cols);
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}
+
+bool caf_doppler_fused_supported(int) { return false; }
 int caf_launch_doppler_fused(const float2*, float2*, int, int, int, hipStream_t) {
     prc_set_error("fused Doppler FFT not built");
     return PRC_EUNSUPPORTED;

@@ -39,3 +39,5 @@ bool caf_fft_supported(int64_t n, int range_bins, int freq_bins, int ntaps_is_bo
 int caf_launch_doppler_fused(const float2* y, float2* out, int freq_bins, int range_bins,
                              int nframes, hipStream_t stream);
 bool caf_doppler_fused_supported(int freq_bins);
+int caf_launch_transpose_jk_kj(const float2* src, float2* dst, int freq_bins, int cols, int nframes,
+                               hipStream_t stream);

@@ -13,7 +13,19 @@ import numpy as np
 
 from . import _lib, engine
 
-__all__ = ["fast_xambg", "caf_plan_for"]
+__all__ = ["fast_xambg", "caf_plan_for", "set_default_methods"]
+
+# Kernel selection used by fast_xambg (0 = let the plan decide).  Not part of the reference
+# signature; tests flip it to run the same cases through every kernel family.
+_DEFAULTS = {"caf": _lib.CAF_AUTO, "doppler": _lib.DOPPLER_AUTO}
+
+
+def set_default_methods(caf=None, doppler=None):
+    """caf: 0 auto | 1 direct | 2 fft;  doppler: 0 auto | 1 rocfft | 2 fused."""
+    if caf is not None:
+        _DEFAULTS["caf"] = int(caf)
+    if doppler is not None:
+        _DEFAULTS["doppler"] = int(doppler)
 
 
 @functools.lru_cache(maxsize=16)
@@ -30,8 +42,11 @@ def _long_taps(q):
     return np.ascontiguousarray(firwin(10 * q + 1, 1.0 / q, window="flattop"), dtype=np.float32)
 
 
-def caf_plan_for(n, rangeBins, freqBins, shortFilt=True, max_frames=1, method=_lib.CAF_AUTO,
-                 doppler=_lib.DOPPLER_AUTO):
+def caf_plan_for(n, rangeBins, freqBins, shortFilt=True, max_frames=1, method=None, doppler=None):
+    method = _DEFAULTS["caf"] if method is None else method
+    doppler = _DEFAULTS["doppler"] if doppler is None else doppler
+    if not shortFilt and method == _lib.CAF_FFT:
+        method = _lib.CAF_AUTO          # the long FIR only exists in the time-domain kernel
     q = int(n / freqBins) if freqBins else 0
     key = ("caf", n, rangeBins, freqBins, bool(shortFilt), max_frames, method, doppler)
     taps = None if shortFilt else _long_taps(q)
