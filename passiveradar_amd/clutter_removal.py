@@ -11,7 +11,13 @@ import numpy as np
 
 from . import _lib, engine
 
-__all__ = ["LS_Filter", "LS_Filter_Toeplitz", "LS_Filter_Multiple", "NLMS_filter"]
+__all__ = ["LS_Filter", "LS_Filter_Toeplitz", "LS_Filter_Multiple", "NLMS_filter", "set_default_ls_method"]
+
+_LS_METHOD = {"m": 0}     # 0 auto | 1 time-domain kernels | 2 FFT kernels (tests flip it)
+
+
+def set_default_ls_method(method):
+    _LS_METHOD["m"] = int(method)
 
 
 def _check_same(ref, srv):
@@ -24,8 +30,9 @@ def _ls_run(ref, srv, filterLen, peek, circular, sampleRate, bins, reg, want_tap
     srv = np.ascontiguousarray(srv, dtype=np.complex64)
     n = ref.shape[0]
     T = int(filterLen) + int(peek)
-    plan = engine.cached_plan(("ls", n, int(filterLen), int(peek), bool(circular)),
-                              lambda: engine.LsPlan(n, filterLen, peek, circular, 1))
+    meth = _LS_METHOD["m"]
+    plan = engine.cached_plan(("ls", n, int(filterLen), int(peek), bool(circular), meth),
+                              lambda: engine.LsPlan(n, filterLen, peek, circular, 1, meth))
     st = engine.staging()
     d_ref = st.get("ls_ref", 8 * n)
     d_srv = st.get("ls_srv", 8 * n)

@@ -58,7 +58,7 @@ struct CafFftArgs {
     int32_t piece;     // B = 1024 - range_bins
 };
 
-__global__ __launch_bounds__(64 * CAFF_WAVES) void caf_fft_kernel(CafFftArgs a) {
+__global__ __launch_bounds__(64 * CAFF_WAVES, 2) void caf_fft_kernel(CafFftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
     float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
@@ -73,48 +73,63 @@ __global__ __launch_bounds__(64 * CAFF_WAVES) void caf_fft_kernel(CafFftArgs a) 
     const float2* __restrict__ ref = a.s.ref + (int64_t)b * a.s.frame_stride;
     const float2* __restrict__ srv = a.s.srv + (int64_t)b * a.s.frame_stride;
     const float* __restrict__ win = a.s.window;
-    const int64_t N = a.s.n, NV = a.s.n_valid;
+    // frame-relative 32-bit offsets everywhere (n < 2^31): uniform 64-bit base + 32-bit lane offset
+    const int N = (int)a.s.n, NV = (int)a.s.n_valid;
     const int R = a.s.range_bins;
     const int B = a.piece;
 
-    const int64_t n_hi = j * a.s.q + a.s.half;
-    const int64_t n_lo = n_hi - (a.s.ntaps - 1);
-    const int64_t lo = n_lo < 0 ? 0 : n_lo;
-    const int64_t hi = n_hi > N - 1 ? N - 1 : n_hi;
+    const int64_t n_hi64 = j * a.s.q + a.s.half;
+    const int64_t n_lo64 = n_hi64 - (a.s.ntaps - 1);
+    const int lo = n_lo64 < 0 ? 0 : (int)n_lo64;
+    const int hi = n_hi64 > N - 1 ? N - 1 : (int)n_hi64;
 
     float2 acc[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) acc[m] = make_float2(0.f, 0.f);
 
-    for (int64_t n0 = lo; n0 <= hi; n0 += B) {
-        const int64_t rem = hi - n0 + 1;
-        const int cnt = rem < B ? (int)rem : B;
+    // Software pipeline: the loads of a piece are issued one FFT ahead of their use and are
+    // branch-free (clamped address + select), so the loop body is one straight-line block:
+    //   [u(i) resident]  issue v(i)  | FFT u(i) |  issue u(i+1), w(i+1)  | FFT v(i) | acc
+    float2 un[16];
+    float wn[16];
+    auto issue_u = [&](int n0) {
+        const int rem = hi - n0 + 1;
+        const int cnt = rem < B ? (rem < 0 ? 0 : rem) : B;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = 64 * r + lane;
+            const int off = n0 + idx;
+            const bool ok = idx < cnt && off < NV;
+            const int oc = ok ? off : 0;
+            un[r] = ref[oc];
+            wn[r] = win ? win[oc] : 1.0f;
+            if (!ok) wn[r] = 0.f;
+        }
+    };
+    issue_u(lo);
+    for (int n0 = lo; n0 <= hi; n0 += B) {
+        const int rem = hi - n0 + 1;
+        const int cnt = rem < B ? rem : B;
         float2 u[16], v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int idx = 64 * r + lane;
-            const int64_t n = n0 + idx;
-            float2 x = make_float2(0.f, 0.f);
-            if (idx < cnt && n < NV) {
-                x = ref[n];
-                if (win) {
-                    const float g = win[n];
-                    x.x *= g;
-                    x.y *= g;
-                }
-            }
-            u[r] = x;
-        }
+        for (int r = 0; r < 16; ++r) u[r] = make_float2(un[r].x * wn[r], un[r].y * wn[r]);
+        bool okv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int idx = 64 * r + lane;
-            int64_t n = n0 + idx;
-            if (n >= N) n %= N;                  // circular wrap of srv inside the frame (:82)
-            float2 x = make_float2(0.f, 0.f);
-            if (idx < cnt + R && n < NV) x = srv[n];
-            v[r] = x;
+            int off = n0 + idx;
+            if (off >= N) off -= N;                     // circular wrap of srv inside the frame (:82)
+            okv[r] = idx < cnt + R && off < NV;
+            v[r] = srv[okv[r] ? off : 0];
         }
+        __builtin_amdgcn_sched_barrier(0);
         fft1024_fwd(u, tile, tab, f);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_u(n0 + B);                                // past the last piece: cnt = 0 -> all lanes read ref[0], masked
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (!okv[r]) v[r] = make_float2(0.f, 0.f);
         fft1024_fwd(v, tile, tab, f);
 #pragma unroll
         for (int m = 0; m < 16; ++m) cmac_conj_a(acc[m], u[m], v[m]);
@@ -150,9 +165,9 @@ __global__ __launch_bounds__(256) void transpose_jk_kj_kernel(const float2* __re
 }
 
 bool caf_fft_supported(int64_t n, int range_bins, int freq_bins, int boxcar) {
-    (void)n;
     (void)freq_bins;
-    return boxcar && range_bins >= 1 && range_bins <= 768;
+    // n >= 2048 keeps a piece's 1024 slots from wrapping around the frame more than once
+    return boxcar && range_bins >= 1 && range_bins <= 768 && n >= 2048;
 }
 
 int caf_launch_fft(const CafSegArgs& s, int nframes, hipStream_t stream) {

@@ -13,7 +13,8 @@
 // With circular=1 the same kernels wrap indices modulo N, which is LS_Filter's circulant data
 // matrix: A^H A is exactly the circular-autocorrelation Toeplitz matrix, so no N x T matrix and
 // no dense GEMM is ever formed.
-#include "common.h"
+#include "ls_internal.h"
+#include <math.h>
 #include <vector>
 
 #define LSC_TILE 1024
@@ -245,6 +246,104 @@ __global__ __launch_bounds__(LS_THREADS) void levinson_kernel(const float2* __re
     for (int k = tid; k < T; k += LS_THREADS) taps_out[(int64_t)b * T + k] = w[k];
 }
 
+// ---- Levinson on ONE wavefront (no workgroup barrier on the T-step critical path) -------------
+// All-lanes sum of a double by DPP: xor-1, xor-2 inside quads, half-row mirror, row mirror (each
+// row of 16 lanes then holds its row sum), then the four row sums are read with v_readlane.
+__device__ __forceinline__ double dpp_add_d(double v, const int ctrl_is) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int plo, phi;
+    switch (ctrl_is) {
+        case 0: plo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+                phi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); break;   // quad xor 1
+        case 1: plo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);
+                phi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); break;   // quad xor 2
+        case 2: plo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true);
+                phi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
+        default: plo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true);
+                 phi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); break; // row_mirror
+    }
+    return v + __hiloint2double(phi, plo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_allsum_d(double v) {
+    v = dpp_add_d(v, 0);
+    v = dpp_add_d(v, 1);
+    v = dpp_add_d(v, 2);
+    v = dpp_add_d(v, 3);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+
+// LDS: c[T], bb[T], a0[T], a1[T], w[T] (double2).  Same recursion as levinson_kernel.
+__global__ __launch_bounds__(64) void levinson_wave_kernel(const float2* __restrict__ partial,
+                                                           int nblk, int T, double reg,
+                                                           double2* __restrict__ taps_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2* c = reinterpret_cast<double2*>(smem_raw);
+    double2* bb = c + T;
+    double2* abuf0 = bb + T;
+    double2* abuf1 = abuf0 + T;
+    double2* w = abuf1 + T;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const float2* part = partial + (int64_t)b * nblk * 2 * T;
+    for (int k = lane; k < T; k += 64) {
+        double cr = 0, ci = 0, br = 0, bi = 0;
+#pragma unroll 4
+        for (int blk = 0; blk < nblk; ++blk) {
+            const float2 u = part[((int64_t)blk * 2 + 0) * T + k];
+            const float2 v = part[((int64_t)blk * 2 + 1) * T + k];
+            cr += (double)u.x; ci += (double)u.y;
+            br += (double)v.x; bi += (double)v.y;
+        }
+        if (k == 0) cr += reg;
+        c[k] = make_double2(cr, -ci);
+        bb[k] = make_double2(br, -bi);
+        abuf0[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
+        abuf1[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
+        w[k] = make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    double err = c[0].x;
+    if (lane == 0) w[0] = zdiv(bb[0], c[0]);
+    __syncthreads();
+    double2* a_old = abuf0;
+    double2* a_new = abuf1;
+    for (int m = 1; m < T; ++m) {
+        double2 acc = make_double2(0, 0), dot = make_double2(0, 0);
+        for (int i = lane; i < m; i += 64) {
+            const double2 cm = c[m - i];
+            acc = zadd(acc, zmul(a_old[i], cm));
+            dot = zadd(dot, zmul(cm, w[i]));
+        }
+        acc.x = wave_allsum_d(acc.x);
+        acc.y = wave_allsum_d(acc.y);
+        dot.x = wave_allsum_d(dot.x);
+        dot.y = wave_allsum_d(dot.y);
+        const double rerr = 1.0 / err;
+        const double2 k = make_double2(-acc.x * rerr, -acc.y * rerr);
+        err = err * (1.0 - (k.x * k.x + k.y * k.y));
+        const double2 res = zsub(bb[m], dot);
+        const double rerr2 = 1.0 / err;
+        const double2 g = make_double2(res.x * rerr2, res.y * rerr2);
+        for (int j = lane; j <= m; j += 64) {
+            const double2 aj = a_old[j];
+            const double2 amj = a_old[m - j];
+            a_new[j] = zadd(aj, zmul(k, zconj(amj)));
+            const double2 anew_mj = zadd(amj, zmul(k, zconj(aj)));
+            w[j] = zadd(w[j], zmul(g, zconj(anew_mj)));
+        }
+        __builtin_amdgcn_wave_barrier();
+        double2* t = a_old;
+        a_old = a_new;
+        a_new = t;
+    }
+    for (int k = lane; k < T; k += 64) taps_out[(int64_t)b * T + k] = w[k];
+}
+
 // ---- FIR apply: out[n] = s[n] - sum_k w[k] r[n-k] ----------------------------------------
 #define FIR_OPT 4
 #define FIR_SPAN (LS_THREADS * FIR_OPT)
@@ -310,7 +409,9 @@ __global__ __launch_bounds__(LS_THREADS) void fir_subtract_kernel(FirArgs a) {
 struct prc_ls_plan {
     prc_ls_desc desc;
     int T;
-    int nblk;
+    int nblk;          // partial-sum slots per block (tiles of the direct kernel / waves of the FFT kernel)
+    int method;        // 1 time-domain, 2 FFT
+    int fft_waves;     // waves per block in the FFT correlation kernel
     float2* d_partial = nullptr;
     double2* d_taps = nullptr;
     float2* d_tmp[2] = {nullptr, nullptr};
@@ -347,7 +448,15 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     prc_ls_plan* p = new prc_ls_plan();
     p->desc = *d;
     p->T = T;
-    p->nblk = (int)ceil_div64(d->n, LSC_BLK);
+    p->method = d->method;
+    if (p->method == 0) p->method = ls_fft_supported(T) ? 2 : 1;
+    if (p->method == 2 && !ls_fft_supported(T)) {
+        prc_set_error("prc_ls_plan_create: FFT method supports at most 769 taps, got %d", T);
+        delete p;
+        return PRC_EUNSUPPORTED;
+    }
+    p->fft_waves = ls_fft_waves_per_block(d->n, T);
+    p->nblk = p->method == 2 ? p->fft_waves : (int)ceil_div64(d->n, LSC_BLK);
     hipError_t e = hipMalloc(&p->d_partial, sizeof(float2) * (size_t)d->max_blocks * p->nblk * 2 * T);
     if (e == hipSuccess) e = hipMalloc(&p->d_taps, sizeof(double2) * (size_t)d->max_blocks * T);
     if (e == hipSuccess) e = hipMalloc(&p->d_tmp[0], sizeof(float2) * (size_t)d->max_blocks * d->n);
@@ -355,6 +464,9 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)levinson_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)levinson_wave_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)fir_subtract_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -423,11 +535,33 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
         ca.pr = pr;
         ca.partial = p->d_partial;
         ca.nblk = p->nblk;
+        const double theta = 2.0 * 3.14159265358979323846 * bins[ib] / sample_rate;
+        if (p->method == 2 && pr.enabled) {
+            PRC_REQUIRE(!p->desc.circular, PRC_EUNSUPPORTED,
+                        "prc_ls_execute: Doppler-shifted bins with the circular (LS_Filter) form need method=1");
+            PRC_REQUIRE(fabs(theta) * (p->desc.peek + 1) <= 0.3, PRC_EUNSUPPORTED,
+                        "prc_ls_execute: |2 pi fc/Fs| * peek = %g too large for the FFT kernels (use method=1)",
+                        fabs(theta) * p->desc.peek);
+        }
+        LsFftArgs xa;
+        xa.ref = (const float2*)ref;  xa.ref_stride = stride;
+        xa.srv = cur;                 xa.srv_stride = cur_stride;
+        xa.out = dst;                 xa.out_stride = dst_stride;
+        xa.partial = p->d_partial;
+        xa.taps = p->d_taps;
+        xa.tab = nullptr;
+        xa.n = n;
+        xa.T = T;
+        xa.peek = p->desc.peek;
+        xa.circular = p->desc.circular;
+        xa.rot = pr.enabled;
+        xa.pr = pr;
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 0], stream));
-        int rc = launch_corr(ca, true, nblocks, stream);
+        int rc = p->method == 2 ? ls_launch_corr_fft(xa, theta, p->fft_waves, nblocks, stream)
+                                : launch_corr(ca, true, nblocks, stream);
         if (rc) return rc;
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 1], stream));
-        hipLaunchKernelGGL(levinson_kernel, dim3(nblocks), dim3(LS_THREADS), levinson_lds(T), stream,
+        hipLaunchKernelGGL(levinson_wave_kernel, dim3(nblocks), dim3(64), levinson_lds(T), stream,
                            p->d_partial, p->nblk, T, reg, p->d_taps);
         PRC_LAUNCH_CHECK();
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
@@ -442,9 +576,14 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
         fa.circular = p->desc.circular;
         fa.rot = pr.enabled;
         fa.pr = pr;
-        dim3 grid((unsigned)ceil_div64(n, FIR_SPAN), (unsigned)nblocks);
-        hipLaunchKernelGGL(fir_subtract_kernel, grid, dim3(LS_THREADS), fir_lds(T), stream, fa);
-        PRC_LAUNCH_CHECK();
+        if (p->method == 2) {
+            rc = ls_launch_fir_fft(xa, theta, nblocks, stream);
+            if (rc) return rc;
+        } else {
+            dim3 grid((unsigned)ceil_div64(n, FIR_SPAN), (unsigned)nblocks);
+            hipLaunchKernelGGL(fir_subtract_kernel, grid, dim3(LS_THREADS), fir_lds(T), stream, fa);
+            PRC_LAUNCH_CHECK();
+        }
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 3], stream));
         cur = dst;
         cur_stride = dst_stride;

@@ -1,0 +1,275 @@
+// FFT-domain kernels of the block least-squares canceller (the HBM-bound form).
+//
+// Same contract as the time-domain kernels in ls.hip (clutter_removal.py:142-155), built on the
+// one-wavefront 1024-point FFT of fft_wave.h:
+//   ls_corr_fft_kernel : lags 0..T-1 of  sum_m conj(r[m]) r[m+k]  and  sum_m conj(r[m]) s[m+k]
+//                        by pieces of B = 1025-T samples: U = FFT(r piece, zero padded),
+//                        V = FFT(r / s piece extended by T-1), accumulate conj(U) V per wave in
+//                        registers, one inverse FFT per wave at the end -> per-wave partial lags
+//                        (scipy.signal.correlate at :142-147; 3 FFTs per piece instead of 2 T
+//                        complex MACs per sample);
+//   ls_fir_fft_kernel  : overlap-save FIR, out = s - IFFT( FFT(r block) * FFT(taps) )   (:153-155).
+// r is the peek-rotated, Doppler-rotated reference generated on the fly: one sincosf per lane per
+// piece at the reference's float32 phase (signal_utils.py:24-27) times a per-register constant
+// step e^{j theta 64 r}; the <= peek samples that wrapped around the block end (np.roll at :139)
+// restart the ramp at index 0 and take a 7th-order Taylor phase (|theta*peek| <= 0.3 enforced on
+// the host).  All loads are branch-free (clamped address + select) and issued one FFT ahead of
+// their use, so each loop body is a single straight-line block the scheduler can overlap.
+#include "ls_internal.h"
+#include "fft_wave.h"
+
+int fftw_device_tables(const float2** out);   // caf_fft.hip
+
+#define LSF_WAVES 4
+
+// exp(j x) for |x| <= 0.3 (error < 2e-9)
+__device__ __forceinline__ float2 small_rot(float x) {
+    const float x2 = x * x;
+    const float c = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f)));
+    const float s = x * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f))));
+    return make_float2(c, s);
+}
+
+struct RefSlot {       // one register slot of the rotated reference, before the data arrived
+    bool ok;           // slot carries a sample (else zero)
+    bool wr;           // source index wrapped around the block end
+    int off;           // clamped source offset into ref
+};
+
+// logical r[m] = ref[(m+peek) mod n] * exp(j phi((m+peek) mod n)),  m may lie outside [0, n)
+__device__ __forceinline__ RefSlot ref_slot(int m, int n, int peek, bool circular, bool want) {
+    RefSlot s;
+    s.wr = false;
+    bool ok = want;
+    if (m >= n) { if (circular) { m -= n; s.wr = true; } else ok = false; }
+    if (m < 0) { if (circular) { m += n; s.wr = true; } else ok = false; }
+    int off = m + peek;
+    if (off >= n) { off -= n; s.wr = true; }
+    s.ok = ok;
+    s.off = ok ? off : 0;
+    return s;
+}
+
+__device__ __forceinline__ float2 ref_finish(float2 raw, const RefSlot& s, int rot, float theta32,
+                                             float2 base, float2 step) {
+    float2 v = raw;
+    if (rot) {
+        const float2 cont = cmul(base, step);
+        const float2 wrapped = small_rot(theta32 * (float)s.off);
+        v = cmul(v, s.wr ? wrapped : cont);
+    }
+    return s.ok ? v : make_float2(0.f, 0.f);
+}
+
+__global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_fft_kernel(LsFftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* tab = reinterpret_cast<float2*>(smem_raw);
+    float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
+    fft_load_tables(tab, a.tab);
+    __syncthreads();
+    const FftLane f = fft_lane_setup();
+    const int lane = f.lane;
+    const int wg = blockIdx.x * LSF_WAVES + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * LSF_WAVES;
+    const int b = blockIdx.y;
+    const float2* __restrict__ ref = a.ref + (int64_t)b * a.ref_stride;
+    const float2* __restrict__ srv = a.srv + (int64_t)b * a.srv_stride;
+    const int n = (int)a.n;
+    const int T = a.T, B = a.piece, ext = T - 1;
+    const bool circ = a.circular != 0;
+
+    float2 wrr[16], wrs[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { wrr[m] = make_float2(0.f, 0.f); wrs[m] = make_float2(0.f, 0.f); }
+
+    const int npieces = (n + B - 1) / B;
+    // pipeline state: raw reference slots of the NEXT piece to process
+    float2 en[16];
+    RefSlot es[16];
+    float2 ebase = make_float2(1.f, 0.f);
+    int ecnt = 0;
+    auto issue_e = [&](int p) {
+        const bool live = p < npieces;
+        const int m0 = live ? p * B : 0;
+        const int rem = n - m0;
+        ecnt = live ? (rem < B ? rem : B) : 0;
+        if (a.rot) ebase = phase_rot(a.pr, (int64_t)m0 + lane + a.peek);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = 64 * r + lane;
+            es[r] = ref_slot(m0 + idx, n, a.peek, circ, idx < ecnt + ext);
+            en[r] = ref[es[r].off];
+        }
+    };
+    issue_e(wg);
+    for (int p = wg; p < npieces; p += nwaves) {
+        const int m0 = p * B;
+        const int cnt = ecnt;
+        float2 u[16], v[16], sv[16];
+        bool oks[16];
+        // issue the surveillance slots of this piece
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = 64 * r + lane;
+            int m = m0 + idx;
+            bool ok = idx < cnt + ext;
+            if (m >= n) { if (circ) m -= n; else ok = false; }
+            oks[r] = ok;
+            sv[r] = srv[ok ? m : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[r] = ref_finish(en[r], es[r], a.rot, a.theta32, ebase, a.step[r]);
+            u[r] = (64 * r + lane) < cnt ? v[r] : make_float2(0.f, 0.f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fft1024_fwd(u, tile, tab, f);
+        fft1024_fwd(v, tile, tab, f);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) cmac_conj_a(wrr[m], u[m], v[m]);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_e(p + nwaves);                      // past the end: all slots masked, reads ref[0]
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = oks[r] ? sv[r] : make_float2(0.f, 0.f);
+        fft1024_fwd(v, tile, tab, f);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) cmac_conj_a(wrs[m], u[m], v[m]);
+    }
+    fft1024_inv(wrr, tile, tab, f);
+    fft1024_inv(wrs, tile, tab, f);
+    // partial[b][wave][0/1][lag] holds conj(g) so that the Levinson prologue's conj() restores g
+    float2* __restrict__ part = a.partial + ((int64_t)b * nwaves + wg) * 2 * T;
+    const float sc = 1.0f / 1024.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lag = 64 * r + lane;
+        if (lag < T) {
+            part[lag] = make_float2(wrr[r].x * sc, -wrr[r].y * sc);
+            part[T + lag] = make_float2(wrs[r].x * sc, -wrs[r].y * sc);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fir_fft_kernel(LsFftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* tab = reinterpret_cast<float2*>(smem_raw);
+    float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
+    fft_load_tables(tab, a.tab);
+    __syncthreads();
+    const FftLane f = fft_lane_setup();
+    const int lane = f.lane;
+    const int wg = blockIdx.x * LSF_WAVES + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * LSF_WAVES;
+    const int b = blockIdx.y;
+    const float2* __restrict__ ref = a.ref + (int64_t)b * a.ref_stride;
+    const float2* __restrict__ srv = a.srv + (int64_t)b * a.srv_stride;
+    float2* __restrict__ out = a.out + (int64_t)b * a.out_stride;
+    const double2* __restrict__ taps = a.taps + (int64_t)b * a.T;
+    const int n = (int)a.n;
+    const int T = a.T, B = a.piece, ext = T - 1;
+    const bool circ = a.circular != 0;
+
+    // H = FFT(taps zero padded) / 1024, once per wave
+    float2 h[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int idx = 64 * r + lane;
+        const double2 t = taps[idx < T ? idx : 0];
+        h[r] = idx < T ? make_float2((float)t.x, (float)t.y) : make_float2(0.f, 0.f);
+    }
+    fft1024_fwd(h, tile, tab, f);
+    const float sc = 1.0f / 1024.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { h[r].x *= sc; h[r].y *= sc; }
+
+    const int nblocks = (n + B - 1) / B;
+    float2 xn[16];
+    RefSlot xs[16];
+    float2 xbase = make_float2(1.f, 0.f);
+    auto issue_x = [&](int p) {
+        const bool live = p < nblocks;
+        const int mstart = (live ? p * B : 0) - ext;       // input index of register slot 0
+        if (a.rot) xbase = phase_rot(a.pr, (int64_t)mstart + lane + a.peek);  // may be negative: e^{j theta i0}
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mstart + 64 * r + lane;
+            xs[r] = ref_slot(m, n, a.peek, circ, live && m < n);
+            xn[r] = ref[xs[r].off];
+        }
+    };
+    issue_x(wg);
+    for (int p = wg; p < nblocks; p += nwaves) {
+        const int n0 = p * B;
+        float2 x[16], sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nn = n0 + 64 * r + lane - ext;
+            sv[r] = srv[(nn >= 0 && nn < n) ? nn : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = ref_finish(xn[r], xs[r], a.rot, a.theta32, xbase, a.step[r]);
+        __builtin_amdgcn_sched_barrier(0);
+        fft1024_fwd(x, tile, tab, f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = cmul(x[r], h[r]);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(p + nwaves);
+        __builtin_amdgcn_sched_barrier(0);
+        fft1024_inv(x, tile, tab, f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = 64 * r + lane;
+            const int nn = n0 + idx - ext;
+            if (idx >= ext && nn < n) out[nn] = make_float2(sv[r].x - x[r].x, sv[r].y - x[r].y);
+        }
+    }
+}
+
+bool ls_fft_supported(int T) { return T >= 2 && T - 1 <= 768; }
+
+int ls_fft_waves_per_block(int64_t n, int T) {
+    // enough waves to fill the chip with a few blocks in flight, but >= ~8 pieces per wave so the
+    // two inverse FFTs per wave stay in the noise
+    const int64_t B = FFTW_P - (T - 1);
+    const int64_t pieces = (n + B - 1) / B;
+    int64_t groups = pieces / (8 * LSF_WAVES);
+    if (groups < 1) groups = 1;
+    if (groups > 16) groups = 16;
+    return (int)groups * LSF_WAVES;
+}
+
+static void fill_common(LsFftArgs& a, int T, double theta) {
+    a.piece = FFTW_P - (T - 1);
+    a.theta32 = (float)theta;
+    for (int r = 0; r < 16; ++r) {
+        const double ang = theta * 64.0 * r;
+        a.step[r] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+}
+
+int ls_launch_corr_fft(LsFftArgs a, double theta, int waves_per_block, int nblocks, hipStream_t stream) {
+    fill_common(a, a.T, theta);
+    int rc = fftw_device_tables(&a.tab);
+    if (rc) return rc;
+    dim3 grid((unsigned)(waves_per_block / LSF_WAVES), (unsigned)nblocks);
+    const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE);
+    hipLaunchKernelGGL(ls_corr_fft_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}
+
+int ls_launch_fir_fft(LsFftArgs a, double theta, int nblocks, hipStream_t stream) {
+    fill_common(a, a.T, theta);
+    int rc = fftw_device_tables(&a.tab);
+    if (rc) return rc;
+    const int64_t B = a.piece;
+    const int64_t pieces = (a.n + B - 1) / B;
+    int64_t groups = (pieces + 4 * LSF_WAVES - 1) / (4 * LSF_WAVES);   // ~4 blocks per wave: H costs 1/9
+    if (groups < 1) groups = 1;
+    dim3 grid((unsigned)groups, (unsigned)nblocks);
+    const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE);
+    hipLaunchKernelGGL(ls_fir_fft_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}

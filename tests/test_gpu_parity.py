@@ -76,6 +76,15 @@ def test_caf_cfg3_digest():
     assert np.abs(out.sum(axis=1) - g["row_sums"]).max() / (peak * np.sqrt(R + 1)) < TOL
 
 
+@pytest.fixture(params=["direct", "fft"])
+def ls_method(request):
+    """run every LS case through both kernel families (time-domain LDS tiles / wavefront FFT)"""
+    from passiveradar_amd import clutter_removal as cr
+    cr.set_default_ls_method({"direct": 1, "fft": 2}[request.param])
+    yield request.param
+    cr.set_default_ls_method(0)
+
+
 @pytest.mark.parametrize("n,R,F,win", [(8192, 70, 128, True), (5000, 4, 51, False), (3000, 129, 8, True),
                                        (65536, 300, 64, True)])
 def test_caf_vs_oracle_shapes(n, R, F, win, caf_method):
@@ -119,7 +128,7 @@ def test_xcorr_and_freqshift():
 
 
 @pytest.mark.parametrize("name", ["ls_toeplitz_white", "ls_toeplitz_peek0", "ls_toeplitz_coloured"])
-def test_ls_toeplitz_golden(name):
+def test_ls_toeplitz_golden(name, ls_method):
     from passiveradar_amd.clutter_removal import LS_Filter_Toeplitz
     g = load_golden(name)
     out, taps = LS_Filter_Toeplitz(g["ref"], g["srv"], int(g["L"]), int(g["peek"]), True)
@@ -128,7 +137,7 @@ def test_ls_toeplitz_golden(name):
     assert rel_err(out, g["out"]) < TIGHT
 
 
-def test_ls_multiple_golden():
+def test_ls_multiple_golden(ls_method):
     from passiveradar_amd.clutter_removal import LS_Filter_Multiple
     g = load_golden("ls_multiple")
     out = LS_Filter_Multiple(g["ref"], g["srv"], int(g["L"]), float(g["fs"]), list(g["bins"]))
@@ -136,7 +145,7 @@ def test_ls_multiple_golden():
 
 
 @pytest.mark.parametrize("name", ["ls_direct", "ls_direct_reg"])
-def test_ls_direct_golden(name):
+def test_ls_direct_golden(name, ls_method):
     from passiveradar_amd.clutter_removal import LS_Filter
     g = load_golden(name)
     out, taps = LS_Filter(g["ref"], g["srv"], int(g["L"]), float(g["reg"]), int(g["peek"]), True)
@@ -145,7 +154,7 @@ def test_ls_direct_golden(name):
     assert rel_err(out, g["out"]) < TOL
 
 
-def test_ls_large_vs_oracle():
+def test_ls_large_vs_oracle(ls_method):
     """multi-tile blocks, T=266 (config-2 taps), five Doppler bins."""
     from passiveradar_amd.clutter_removal import LS_Filter_Multiple, LS_Filter_Toeplitz
     n, L = 150000, 256
