@@ -109,6 +109,7 @@ class HipBackend:
             else:
                 w = None if window is None else np.ascontiguousarray(window, dtype=np.float32)
             self.window = None if w is None else torch.from_numpy(w).to(self.device)
+        self._clean_buf = None
 
     def _stream(self):
         from . import _lib
@@ -130,7 +131,11 @@ class HipBackend:
         C, h = self.C, self.C // 2
         if self.clutter is None:
             return srv_pad
-        out = torch.zeros_like(srv_pad)
+        # cleaned stream buffer is reused across calls; only its two C/2 pads must be zero and the
+        # kernels never write them
+        out = self._clean_buf
+        if out is None or out.shape != srv_pad.shape or out.device != srv_pad.device:
+            out = self._clean_buf = torch.zeros_like(srv_pad)
         with torch.cuda.device(self.device):
             for c0 in range(0, nlocal, self.batch):
                 nb = min(self.batch, nlocal - c0)

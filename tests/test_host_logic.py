@@ -1,0 +1,103 @@
+"""Host-side logic that needs no GPU: config derivation vs the reference's dict, scene generator,
+frame sharding arithmetic, argument validation that happens before any device call."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+from passiveradar_amd import scene
+from passiveradar_amd.config import derive, getConfiguration, nearestpow2, nextpow2
+from passiveradar_amd.stream import plan_shard
+
+REF_YAML = """
+input_file: 'PassiveRadar_20191102_1011.hdf5'
+interleaved_input_channels: False
+input_ref_path: '/data/ref'
+input_srv_path: '/data/srv'
+interleaved_data_path: '/data'
+range_doppler_map_ftype: 'zarr'
+output_fname: 'XAMBG_1011'
+num_frames: 1200
+input_sample_rate: 2400000
+input_center_freq: 102000000
+channel_freq: 101900000
+channel_bandwidth: 200000
+cpi_seconds_nominal: 2.0
+max_doppler_nominal: 256.0
+max_range_nominal: 200.0
+overlap_cpi: True
+"""
+
+
+def _same(a, b):
+    if isinstance(a, float) or isinstance(b, float):
+        return a == pytest.approx(b, rel=1e-15, abs=0)
+    return a == b
+
+
+def test_config_matches_reference_dict(tmp_path):
+    gold = json.load(open(os.path.join(GOLDEN, "config_prconfig.json")))
+    p = tmp_path / "PRconfig.yaml"
+    p.write_text(REF_YAML)
+    cfg = getConfiguration(str(p))
+    assert set(cfg) == set(gold)
+    for k in gold:
+        assert _same(cfg[k], gold[k]), k
+    assert cfg["cpi_samples"] == 524288 and cfg["num_range_cells"] == 175 and cfg["num_doppler_cells"] == 1024
+
+
+def test_config_cfg1_variant(tmp_path):
+    import yaml
+    g = json.load(open(os.path.join(GOLDEN, "config_cfg1.json")))
+    base = yaml.safe_load(REF_YAML)
+    base.update(g["yaml_overrides"])
+    cfg = derive(base)
+    for k, v in g["derived"].items():
+        assert _same(cfg[k], v), k
+    assert (cfg["cpi_samples"], cfg["num_range_cells"], cfg["num_doppler_cells"]) == (262144, 256, 256)
+
+
+def test_config_non_overlap_wart_is_kept(tmp_path):
+    import yaml
+    base = yaml.safe_load(REF_YAML)
+    base["overlap_cpi"] = False
+    with pytest.raises(KeyError):          # config.py:77 reads config['cpi']
+        derive(base)
+
+
+def test_pow2_helpers():
+    assert [nextpow2(i) for i in (1, 2, 3, 400000)] == [1, 2, 4, 524288]
+    assert [nearestpow2(i) for i in (3, 5, 6, 7, 1023.8)] == [2, 4, 4, 8, 1024]
+
+
+def test_scene_is_deterministic_and_peaks_where_expected():
+    a1, s1 = scene.make_scene(4096, 8000.0, 20, 123)
+    a2, s2 = scene.make_scene(4096, 8000.0, 20, 123)
+    assert np.array_equal(a1, a2) and np.array_equal(s1, s2) and a1.dtype == np.complex64
+    assert abs(np.mean(np.abs(a1) ** 2) - 1.0) < 0.05
+    assert scene.expected_peak_cell(7, 5.0, 4096, 4096, 20, 64) == (27, 13)
+
+
+@pytest.mark.parametrize("nchunks,world", [(1199, 8), (6, 2), (5, 4), (3, 8), (16, 1)])
+def test_plan_shard_covers_every_frame_once(nchunks, world):
+    seen = []
+    for r in range(world):
+        sh = plan_shard(nchunks, r, world)
+        seen += list(range(sh.frame_lo, sh.frame_hi))
+        if sh.nframes:
+            # every chunk a frame touches (i-1, i, i+1, clipped) is resident on the rank
+            assert sh.chunk_lo == max(sh.frame_lo - 1, 0) and sh.chunk_hi == min(sh.frame_hi + 1, nchunks)
+            assert sh.frame_offset(sh.frame_lo, 8) == (sh.frame_lo - sh.chunk_lo) * 8
+    assert seen == list(range(nchunks))
+
+
+def test_shape_errors_are_raised_before_any_device_call():
+    from passiveradar_amd.clutter_removal import LS_Filter, LS_Filter_Multiple, LS_Filter_Toeplitz
+    from passiveradar_amd.range_doppler_processing import fast_xambg
+    a, b = np.zeros(64, np.complex64), np.zeros(63, np.complex64)
+    for fn in (lambda: fast_xambg(a, b, 3, 8), lambda: LS_Filter_Toeplitz(a, b, 4),
+               lambda: LS_Filter_Multiple(a, b, 4, 1e3), lambda: LS_Filter(a, b, 4)):
+        with pytest.raises(ValueError):
+            fn()
