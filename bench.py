@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--caf-method", type=int, default=0, help="0 auto, 1 direct, 2 fft")
     ap.add_argument("--doppler", type=int, default=0, help="0 auto, 1 rocfft, 2 fused")
+    ap.add_argument("--ls-streams", type=int, default=2, help="HIP streams the LS half-batches run on")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-clutter", action="store_true", help="CAF only (reported as a different metric)")
     args = ap.parse_args()
@@ -132,7 +133,7 @@ def main():
     B = args.frames
     C = n // 2
     be = prstream.HipBackend(n, R, F, fs, clutter=clutter, batch=B, device=device,
-                             caf_method=args.caf_method, doppler_method=args.doppler)
+                             caf_method=args.caf_method, doppler_method=args.doppler, ls_streams=args.ls_streams)
     ref, srv = synth_stream(torch, B, C, fs, R, 20260926 + rank, device)
     ref_pad = be.padded(ref)
     srv_pad = be.padded(srv)

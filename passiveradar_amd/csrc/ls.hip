@@ -344,6 +344,222 @@ __global__ __launch_bounds__(64) void levinson_wave_kernel(const float2* __restr
     for (int k = lane; k < T; k += 64) taps_out[(int64_t)b * T + k] = w[k];
 }
 
+// ---- shared-inverse solve for the Doppler-bin chain --------------------------------------------
+// LS_Filter_Multiple (clutter_removal.py:178-187) solves Toeplitz(c_f) w = b_f once per Doppler bin
+// with r_f = roll(ref e^{j phi_f}, -peek).  With rho = roll(ref, -peek), theta = 2 pi f/Fs and
+// gamma = e^{-j theta N} (the phase ramp restarts for the `peek` samples that wrapped around):
+//     c_f[k] = e^{j theta k} ( c_0[k] + (gamma - 1) S_e[k] ),
+//     S_e[k] = sum_{n >= max(N-peek,k), n-k < N-peek} rho[n] conj(rho[n-k])          (<= peek terms)
+// so the T sequential Levinson-Durbin steps run ONCE per block (ls_prepare_kernel: forward
+// predictor -> dense T_0^{-1} by the Trench recurrence), and every bin is a fully parallel
+//     w = D T_0^{-1} D^H b_f  (+ refinement steps against the exact c_f),   D = diag(e^{j theta k})
+// (ls_solve_kernel).  Checked identity by identity in tools/ls_shared_inverse_model.py.
+struct LsPrepArgs {
+    const float2* partial;   // [block][nblk][2][T], slot 0 = conj(autocorrelation of the bin-0 reference)
+    const float2* ref;
+    int64_t ref_stride;
+    int64_t n;
+    int32_t nblk, T, peek;
+    double reg;
+    double theta0;           // rotation of the reference the autocorrelation was taken with
+    double2* c0;             // [block][T]
+    double2* se;             // [block][T]
+    double2* tinv;           // [block][T][T]
+};
+
+__global__ __launch_bounds__(LS_THREADS) void ls_prepare_kernel(LsPrepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2* c = reinterpret_cast<double2*>(smem_raw);
+    double2* abuf0 = c + a.T;
+    double2* abuf1 = abuf0 + a.T;
+    double2* scratch = abuf1 + a.T;                    // [0] = (err, which buffer holds the predictor)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, T = a.T;
+    const float2* part = a.partial + (int64_t)b * a.nblk * 2 * T;
+    const float2* ref = a.ref + (int64_t)b * a.ref_stride;
+    const int64_t N = a.n;
+    const double g0x = cos(-a.theta0 * (double)N) - 1.0, g0y = sin(-a.theta0 * (double)N);   // gamma0 - 1
+    for (int k = tid; k < T; k += LS_THREADS) {
+        double cr = 0, ci = 0;
+#pragma unroll 4
+        for (int blk = 0; blk < a.nblk; ++blk) {
+            const float2 u = part[((int64_t)blk * 2 + 0) * T + k];
+            cr += (double)u.x;
+            ci += (double)u.y;
+        }
+        // S_e[k]: n wrapped (rho[n] = ref[n+peek-N]), n-k not wrapped (rho[n-k] = ref[n-k+peek])
+        double sr = 0, si = 0;
+        for (int64_t n = (N - a.peek > k ? N - a.peek : k); n < N; ++n) {
+            if (n - k >= N - a.peek) continue;
+            const float2 x = ref[n + a.peek - N], y = ref[n - k + a.peek];
+            sr += (double)x.x * y.x + (double)x.y * y.y;
+            si += (double)x.y * y.x - (double)x.x * y.y;
+        }
+        // c_0[k] = e^{-j theta0 k} c_f0[k] - (gamma0 - 1) S_e[k]
+        double sn, cs;
+        sincos(-a.theta0 * (double)k, &sn, &cs);
+        const double2 cf0 = make_double2(cr, -ci);
+        double2 c0 = zmul(make_double2(cs, sn), cf0);
+        c0 = zsub(c0, zmul(make_double2(g0x, g0y), make_double2(sr, si)));
+        if (k == 0) c0.x += a.reg;
+        c[k] = c0;
+        a.c0[(int64_t)b * T + k] = c0;
+        a.se[(int64_t)b * T + k] = make_double2(sr, si);
+        abuf0[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
+        abuf1[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
+    }
+    __syncthreads();
+    // Levinson-Durbin forward recursion on wavefront 0 (T sequential steps, no workgroup barrier)
+    if (wave == 0) {
+        double err = c[0].x;
+        double2* a_old = abuf0;
+        double2* a_new = abuf1;
+        for (int m = 1; m < T; ++m) {
+            double2 acc = make_double2(0, 0);
+            for (int i = lane; i < m; i += 64) acc = zadd(acc, zmul(a_old[i], c[m - i]));
+            acc.x = wave_allsum_d(acc.x);
+            acc.y = wave_allsum_d(acc.y);
+            const double rerr = 1.0 / err;
+            const double2 k = make_double2(-acc.x * rerr, -acc.y * rerr);
+            err = err * (1.0 - (k.x * k.x + k.y * k.y));
+            for (int j = lane; j <= m; j += 64)
+                a_new[j] = zadd(a_old[j], zmul(k, zconj(a_old[m - j])));
+            __builtin_amdgcn_wave_barrier();
+            double2* t = a_old;
+            a_old = a_new;
+            a_new = t;
+        }
+        if (lane == 0) scratch[0] = make_double2(err, (a_old == abuf0) ? 0.0 : 1.0);
+    }
+    __syncthreads();
+    const double2* af = scratch[0].y != 0.0 ? abuf1 : abuf0;   // forward predictor, af[0] = 1
+    const double ie = 1.0 / scratch[0].x;              // x = af / err is the first column of T_0^{-1}
+    double2* tinv = a.tinv + (int64_t)b * T * T;
+    // Trench recurrence along the diagonals of the lower triangle (i = j + d), mirrored by symmetry:
+    //   inv[i+1][j+1] = inv[i][j] + ( x[i+1] conj(x[j+1]) - conj(x[T-1-i]) x[T-1-j] ) / x[0]
+    for (int d = tid; d < T; d += LS_THREADS) {
+        double2 v = zscale(af[d], ie);                 // inv[d][0] = x[d]
+        tinv[(int64_t)d * T] = v;
+        tinv[d] = zconj(v);
+        for (int j = 0; j + 1 + d < T; ++j) {
+            const int i = j + d;
+            const double2 t1 = zmul(af[i + 1], zconj(af[j + 1]));
+            const double2 t2 = zmul(zconj(af[T - 1 - i]), af[T - 1 - j]);
+            v = zadd(v, zscale(zsub(t1, t2), ie));     // (x x^H - xr xr^H)/x0 with x = af/err, x0 = 1/err
+            tinv[(int64_t)(i + 1) * T + (j + 1)] = v;
+            tinv[(int64_t)(j + 1) * T + (i + 1)] = zconj(v);
+        }
+    }
+}
+
+struct LsSolveArgs {
+    const float2* partial;   // slot 1 = conj(cross-correlation with the current surveillance stream)
+    const double2* c0;
+    const double2* se;
+    const double2* tinv;
+    double2* taps;           // [block][T]
+    int64_t n;
+    int32_t nblk, T, nref;
+    double theta;            // rotation of this bin (effective float32 ramp slope)
+};
+
+#define LSS_THREADS 1024
+__global__ __launch_bounds__(LSS_THREADS) void ls_solve_kernel(LsSolveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2* bb = reinterpret_cast<double2*>(smem_raw);   // right-hand side
+    double2* cf = bb + a.T;                                // exact first column for this bin
+    double2* v = cf + a.T;                                 // D^H (rhs or residual)
+    double2* x = v + a.T;                                  // solution
+    double2* dd = x + a.T;                                 // D[k] = e^{j theta k}
+    double2* pacc = dd + a.T;                              // [parts][RP] partial row sums
+    const int tid = threadIdx.x, b = blockIdx.x, T = a.T;
+    // rows are spread over RP = T rounded up to a wavefront; the column range is cut into `parts`
+    const int RP = (T + 63) & ~63;
+    const int parts = LSS_THREADS / RP > 0 ? LSS_THREADS / RP : 1;
+    const int row = tid % RP, part = tid / RP;
+    const int span = (T + parts - 1) / parts;
+    const int j0 = part * span, j1 = (j0 + span < T) ? j0 + span : T;
+    const bool active = part < parts && row < T;
+    const float2* part_sum = a.partial + (int64_t)b * a.nblk * 2 * T;
+    const double2* tinv = a.tinv + (int64_t)b * T * T;
+    const double gx = cos(-a.theta * (double)a.n) - 1.0, gy = sin(-a.theta * (double)a.n);
+    for (int k = tid; k < T; k += LSS_THREADS) {
+        double br = 0, bi = 0;
+#pragma unroll 4
+        for (int blk = 0; blk < a.nblk; ++blk) {
+            const float2 u = part_sum[((int64_t)blk * 2 + 1) * T + k];
+            br += (double)u.x;
+            bi += (double)u.y;
+        }
+        double sn, cs;
+        sincos(a.theta * (double)k, &sn, &cs);
+        const double2 D = make_double2(cs, sn);
+        const double2 rhs = make_double2(br, -bi);
+        bb[k] = rhs;
+        dd[k] = D;
+        v[k] = zmul(zconj(D), rhs);
+        const double2 base = zadd(a.c0[(int64_t)b * T + k],
+                                  zmul(make_double2(gx, gy), a.se[(int64_t)b * T + k]));
+        cf[k] = zmul(D, base);
+    }
+    __syncthreads();
+    for (int it = 0; it <= a.nref; ++it) {
+        // x (+)= D T_0^{-1} v   (T_0^{-1} is Hermitian: column `row` is read as conj(row-major [j][row]),
+        // consecutive threads on consecutive addresses; 8 independent loads in flight per thread)
+        if (active) {
+            double2 acc = make_double2(0, 0), acc2 = make_double2(0, 0);
+            const double2* col = tinv + row;
+            int j = j0;
+            for (; j + 8 <= j1; j += 8) {
+                double2 t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = col[(int64_t)(j + q) * T];
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) {
+                    acc = zadd(acc, zmul(zconj(t[q]), v[j + q]));
+                    acc2 = zadd(acc2, zmul(zconj(t[q + 1]), v[j + q + 1]));
+                }
+            }
+            for (; j < j1; ++j) acc = zadd(acc, zmul(zconj(col[(int64_t)j * T]), v[j]));
+            pacc[part * RP + row] = zadd(acc, acc2);
+        }
+        __syncthreads();
+        if (tid < T) {
+            double2 acc = pacc[tid];
+            for (int q = 1; q < parts; ++q) acc = zadd(acc, pacc[q * RP + tid]);
+            acc = zmul(dd[tid], acc);
+            x[tid] = it == 0 ? acc : zadd(x[tid], acc);
+        }
+        __syncthreads();
+        if (it == a.nref) break;
+        // residual against the exact Toeplitz(c_f):  v = D^H ( b - T_f x )
+        if (active) {
+            double2 acc = make_double2(0, 0), acc2 = make_double2(0, 0);
+            int j = j0;
+            for (; j + 2 <= j1; j += 2) {
+                const int d0 = row - j, d1 = row - j - 1;
+                const double2 c0 = d0 >= 0 ? cf[d0] : zconj(cf[-d0]);
+                const double2 c1 = d1 >= 0 ? cf[d1] : zconj(cf[-d1]);
+                acc = zadd(acc, zmul(c0, x[j]));
+                acc2 = zadd(acc2, zmul(c1, x[j + 1]));
+            }
+            for (; j < j1; ++j) {
+                const int d = row - j;
+                acc = zadd(acc, zmul(d >= 0 ? cf[d] : zconj(cf[-d]), x[j]));
+            }
+            pacc[part * RP + row] = zadd(acc, acc2);
+        }
+        __syncthreads();
+        if (tid < T) {
+            double2 acc = bb[tid];
+            for (int q = 0; q < parts; ++q) acc = zsub(acc, pacc[q * RP + tid]);
+            v[tid] = zmul(zconj(dd[tid]), acc);
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < T; k += LSS_THREADS) a.taps[(int64_t)b * T + k] = x[k];
+}
+
 // ---- FIR apply: out[n] = s[n] - sum_k w[k] r[n-k] ----------------------------------------
 #define FIR_OPT 4
 #define FIR_SPAN (LS_THREADS * FIR_OPT)
@@ -415,6 +631,10 @@ struct prc_ls_plan {
     float2* d_partial = nullptr;
     double2* d_taps = nullptr;
     float2* d_tmp[2] = {nullptr, nullptr};
+    // shared-inverse path (non-circular FFT chain): c_0, S_e, dense T_0^{-1} per block
+    double2* d_c0 = nullptr;
+    double2* d_se = nullptr;
+    double2* d_tinv = nullptr;
     // optional per-kernel timing (bench.py roofline): events around every launch of one execute
     int profiling = 0;
     std::vector<hipEvent_t> ev;     // 4 per Doppler bin: before corr, after corr, after levinson, after fir
@@ -428,6 +648,9 @@ extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_tmp[0]) (void)hipFree(p->d_tmp[0]);
     if (p->d_tmp[1]) (void)hipFree(p->d_tmp[1]);
+    if (p->d_c0) (void)hipFree(p->d_c0);
+    if (p->d_se) (void)hipFree(p->d_se);
+    if (p->d_tinv) (void)hipFree(p->d_tinv);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
     return PRC_OK;
@@ -464,6 +687,15 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)levinson_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024);
+    if (e == hipSuccess && p->method == 2 && !d->circular) {
+        e = hipMalloc(&p->d_c0, sizeof(double2) * (size_t)d->max_blocks * T);
+        if (e == hipSuccess) e = hipMalloc(&p->d_se, sizeof(double2) * (size_t)d->max_blocks * T);
+        if (e == hipSuccess) e = hipMalloc(&p->d_tinv, sizeof(double2) * (size_t)d->max_blocks * T * T);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)ls_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)ls_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)levinson_wave_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -557,13 +789,44 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
         xa.rot = pr.enabled;
         xa.pr = pr;
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 0], stream));
-        int rc = p->method == 2 ? ls_launch_corr_fft(xa, theta, p->fft_waves, nblocks, stream)
+        // shared-inverse path: the wrap perturbation (gamma-1) S_e must be small against c_0 for the
+        // refinement to converge fast (ratio ~ peek/N); short blocks keep the per-bin Levinson solve
+        const bool shared = p->d_tinv && nbins > 1 && n >= 2000LL * (p->desc.peek > 0 ? p->desc.peek : 1);
+        int rc = p->method == 2 ? ls_launch_corr_fft(xa, theta, p->fft_waves, nblocks, !(shared && ib > 0), stream)
                                 : launch_corr(ca, true, nblocks, stream);
         if (rc) return rc;
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 1], stream));
-        hipLaunchKernelGGL(levinson_wave_kernel, dim3(nblocks), dim3(64), levinson_lds(T), stream,
-                           p->d_partial, p->nblk, T, reg, p->d_taps);
-        PRC_LAUNCH_CHECK();
+        if (shared) {
+            // effective slope of the reference's float32 ramp: fl32(2 pi f) * fl32(1/Fs)
+            const double theta_eff = (double)pr.a32 * (double)pr.rcp32;
+            if (ib == 0) {
+                LsPrepArgs pa;
+                pa.partial = p->d_partial;  pa.ref = (const float2*)ref;  pa.ref_stride = stride;
+                pa.n = n;  pa.nblk = p->nblk;  pa.T = T;  pa.peek = p->desc.peek;  pa.reg = reg;
+                pa.theta0 = pr.enabled ? theta_eff : 0.0;
+                pa.c0 = p->d_c0;  pa.se = p->d_se;  pa.tinv = p->d_tinv;
+                hipLaunchKernelGGL(ls_prepare_kernel, dim3(nblocks), dim3(LS_THREADS),
+                                   sizeof(double2) * ((size_t)3 * T + 1), stream, pa);
+                PRC_LAUNCH_CHECK();
+            }
+            LsSolveArgs sa;
+            sa.partial = p->d_partial;  sa.c0 = p->d_c0;  sa.se = p->d_se;  sa.tinv = p->d_tinv;
+            sa.taps = p->d_taps;  sa.n = n;  sa.nblk = p->nblk;  sa.T = T;
+            sa.theta = pr.enabled ? theta_eff : 0.0;
+            // one refinement squares the wrap perturbation (~ a few peek/N); two for short blocks
+            sa.nref = !pr.enabled ? 0 : (n >= 100000LL * (p->desc.peek > 0 ? p->desc.peek : 1) ? 1 : 2);
+            {
+                const int RP = (T + 63) & ~63;
+                const int parts = LSS_THREADS / RP > 0 ? LSS_THREADS / RP : 1;
+                hipLaunchKernelGGL(ls_solve_kernel, dim3(nblocks), dim3(LSS_THREADS),
+                                   sizeof(double2) * ((size_t)5 * T + (size_t)parts * RP), stream, sa);
+            }
+            PRC_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(levinson_wave_kernel, dim3(nblocks), dim3(64), levinson_lds(T), stream,
+                               p->d_partial, p->nblk, T, reg, p->d_taps);
+            PRC_LAUNCH_CHECK();
+        }
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
         FirArgs fa;
         fa.ref = (const float2*)ref;  fa.ref_stride = stride;

@@ -61,6 +61,9 @@ __device__ __forceinline__ float2 ref_finish(float2 raw, const RefSlot& s, int r
     return s.ok ? v : make_float2(0.f, 0.f);
 }
 
+// AUTO: also accumulate the reference autocorrelation (3 FFTs per piece); otherwise only the
+// cross-correlation with the surveillance stream (2 FFTs per piece, shared-inverse chain).
+template <bool AUTO>
 __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_fft_kernel(LsFftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
@@ -124,9 +127,11 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_fft_kernel(LsFftArg
         }
         __builtin_amdgcn_sched_barrier(0);
         fft1024_fwd(u, tile, tab, f);
-        fft1024_fwd(v, tile, tab, f);
+        if (AUTO) {
+            fft1024_fwd(v, tile, tab, f);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) cmac_conj_a(wrr[m], u[m], v[m]);
+            for (int m = 0; m < 16; ++m) cmac_conj_a(wrr[m], u[m], v[m]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         issue_e(p + nwaves);                      // past the end: all slots masked, reads ref[0]
         __builtin_amdgcn_sched_barrier(0);
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_fft_kernel(LsFftArg
 #pragma unroll
         for (int m = 0; m < 16; ++m) cmac_conj_a(wrs[m], u[m], v[m]);
     }
-    fft1024_inv(wrr, tile, tab, f);
+    if (AUTO) fft1024_inv(wrr, tile, tab, f);
     fft1024_inv(wrs, tile, tab, f);
     // partial[b][wave][0/1][lag] holds conj(g) so that the Levinson prologue's conj() restores g
     float2* __restrict__ part = a.partial + ((int64_t)b * nwaves + wg) * 2 * T;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_fft_kernel(LsFftArg
     for (int r = 0; r < 16; ++r) {
         const int lag = 64 * r + lane;
         if (lag < T) {
-            part[lag] = make_float2(wrr[r].x * sc, -wrr[r].y * sc);
+            if (AUTO) part[lag] = make_float2(wrr[r].x * sc, -wrr[r].y * sc);
             part[T + lag] = make_float2(wrs[r].x * sc, -wrs[r].y * sc);
         }
     }
@@ -248,13 +253,17 @@ static void fill_common(LsFftArgs& a, int T, double theta) {
     }
 }
 
-int ls_launch_corr_fft(LsFftArgs a, double theta, int waves_per_block, int nblocks, hipStream_t stream) {
+int ls_launch_corr_fft(LsFftArgs a, double theta, int waves_per_block, int nblocks, bool with_autocorr,
+                       hipStream_t stream) {
     fill_common(a, a.T, theta);
     int rc = fftw_device_tables(&a.tab);
     if (rc) return rc;
     dim3 grid((unsigned)(waves_per_block / LSF_WAVES), (unsigned)nblocks);
     const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE);
-    hipLaunchKernelGGL(ls_corr_fft_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    if (with_autocorr)
+        hipLaunchKernelGGL(ls_corr_fft_kernel<true>, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    else
+        hipLaunchKernelGGL(ls_corr_fft_kernel<false>, grid, dim3(64 * LSF_WAVES), lds, stream, a);
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }

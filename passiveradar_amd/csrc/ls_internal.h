@@ -19,5 +19,6 @@ struct LsFftArgs {
 
 bool ls_fft_supported(int T);
 int ls_fft_waves_per_block(int64_t n, int T);
-int ls_launch_corr_fft(LsFftArgs a, double theta, int waves_per_block, int nblocks, hipStream_t stream);
+int ls_launch_corr_fft(LsFftArgs a, double theta, int waves_per_block, int nblocks, bool with_autocorr,
+                       hipStream_t stream);
 int ls_launch_fir_fft(LsFftArgs a, double theta, int nblocks, hipStream_t stream);

@@ -23,6 +23,11 @@ import numpy as np
 __all__ = ["Shard", "plan_shard", "gather_frames", "HipBackend", "StreamProcessor"]
 
 
+def C_void(ptr):
+    import ctypes
+    return ctypes.c_void_p(ptr)
+
+
 @dataclass(frozen=True)
 class Shard:
     rank: int
@@ -84,7 +89,7 @@ class HipBackend:
 
     def __init__(self, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
                  doppler_bins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), clutter="ls",
-                 batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02):
+                 batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, ls_streams=2):
         import torch
         from . import engine
         from .range_doppler_processing import _named_window
@@ -102,8 +107,18 @@ class HipBackend:
         with torch.cuda.device(self.device):
             self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch, caf_method, doppler_method)
             self.ls = None
+            self.ls_lanes = []
             if clutter == "ls":
-                self.ls = engine.LsPlan(self.C, self.R, 10, False, self.batch)
+                # The Levinson solve of a batch occupies <= batch wavefronts for ~T sequential
+                # steps; two half-batches on two HIP streams let one half's solve hide under the
+                # other half's correlation / FIR kernels.
+                self.nlanes = 2 if self.batch >= 8 and ls_streams >= 2 else 1
+                per = -(-self.batch // self.nlanes)
+                for _ in range(self.nlanes):
+                    self.ls_lanes.append((engine.LsPlan(self.C, self.R, 10, False, per),
+                                          torch.cuda.Stream(device=self.device)))
+                self.ls = self.ls_lanes[0][0]
+                self.ls_per = per
             if isinstance(window, (tuple, str)):
                 w = _named_window(window, self.cpi)
             else:
@@ -140,9 +155,24 @@ class HipBackend:
             for c0 in range(0, nlocal, self.batch):
                 nb = min(self.batch, nlocal - c0)
                 off = h + c0 * C
-                if self.clutter == "ls":
+                if self.clutter == "ls" and self.nlanes == 1:
                     self.ls.execute(ref_pad[off:], srv_pad[off:], out[off:], nb, C, C, self.fs,
                                     self.bins, 0.0, None, self._stream())
+                elif self.clutter == "ls":
+                    main = torch.cuda.current_stream()
+                    done = []
+                    for li, (plan, st) in enumerate(self.ls_lanes):
+                        b0 = li * self.ls_per
+                        nl = min(self.ls_per, nb - b0)
+                        if nl <= 0:
+                            break
+                        st.wait_stream(main)
+                        o2 = off + b0 * C
+                        plan.execute(ref_pad[o2:], srv_pad[o2:], out[o2:], nl, C, C, self.fs,
+                                     self.bins, 0.0, None, C_void(st.cuda_stream))
+                        done.append(st)
+                    for st in done:
+                        main.wait_stream(st)
                 else:
                     self.engine.nlms_execute(ref_pad[off:], srv_pad[off:], out[off:], C, self.R,
                                              self.nlms_mu, 10, None, None, nb, C, C, self._stream())
