@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=16, help="frames (= hop chunks) per GPU per step")
+    ap.add_argument("--frames", type=int, default=64, help="frames (= hop chunks) per GPU per step")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--caf-method", type=int, default=0, help="0 auto, 1 direct, 2 fft")
     ap.add_argument("--doppler", type=int, default=0, help="0 auto, 1 rocfft, 2 fused")
@@ -220,6 +220,8 @@ def main():
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+                if traffic is not None:
+                    traffic = traffic * B          # file holds bytes per chunk/frame; one launch covers B
             except Exception:
                 traffic = None
         per_frame_bytes = 20.0 * n + 8.0 * F * (R + 1) + (200.0 * C if clutter == "ls" else

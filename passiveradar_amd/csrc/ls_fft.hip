@@ -64,7 +64,7 @@ __device__ __forceinline__ float2 ref_finish(float2 raw, const RefSlot& s, int r
 // AUTO: also accumulate the reference autocorrelation (3 FFTs per piece); otherwise only the
 // cross-correlation with the surveillance stream (2 FFTs per piece, shared-inverse chain).
 template <bool AUTO>
-__global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_fft_kernel(LsFftArgs a) {
+__global__ __launch_bounds__(64 * LSF_WAVES, AUTO ? 1 : 2) void ls_corr_fft_kernel(LsFftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
     float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
@@ -109,17 +109,6 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_fft_kernel(LsFftArg
         const int m0 = p * B;
         const int cnt = ecnt;
         float2 u[16], v[16], sv[16];
-        bool oks[16];
-        // issue the surveillance slots of this piece
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int idx = 64 * r + lane;
-            int m = m0 + idx;
-            bool ok = idx < cnt + ext;
-            if (m >= n) { if (circ) m -= n; else ok = false; }
-            oks[r] = ok;
-            sv[r] = srv[ok ? m : 0];
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             v[r] = ref_finish(en[r], es[r], a.rot, a.theta32, ebase, a.step[r]);
@@ -127,6 +116,17 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_fft_kernel(LsFftArg
         }
         __builtin_amdgcn_sched_barrier(0);
         fft1024_fwd(u, tile, tab, f);
+        __builtin_amdgcn_sched_barrier(0);
+        // issue the surveillance slots of this piece (consumed one or two FFTs later)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = 64 * r + lane;
+            int m = m0 + idx;
+            bool ok = idx < cnt + ext;
+            if (m >= n) { if (circ) m -= n; else ok = false; }
+            sv[r] = srv[ok ? m : 0];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (AUTO) {
             fft1024_fwd(v, tile, tab, f);
 #pragma unroll
@@ -136,7 +136,11 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_fft_kernel(LsFftArg
         issue_e(p + nwaves);                      // past the end: all slots masked, reads ref[0]
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = oks[r] ? sv[r] : make_float2(0.f, 0.f);
+        for (int r = 0; r < 16; ++r) {
+            const int idx = 64 * r + lane;
+            const bool ok = idx < cnt + ext && (circ || m0 + idx < n);
+            v[r] = ok ? sv[r] : make_float2(0.f, 0.f);
+        }
         fft1024_fwd(v, tile, tab, f);
 #pragma unroll
         for (int m = 0; m < 16; ++m) cmac_conj_a(wrs[m], u[m], v[m]);
@@ -274,7 +278,7 @@ int ls_launch_fir_fft(LsFftArgs a, double theta, int nblocks, hipStream_t stream
     if (rc) return rc;
     const int64_t B = a.piece;
     const int64_t pieces = (a.n + B - 1) / B;
-    int64_t groups = (pieces + 4 * LSF_WAVES - 1) / (4 * LSF_WAVES);   // ~4 blocks per wave: H costs 1/9
+    int64_t groups = (pieces + 16 * LSF_WAVES - 1) / (16 * LSF_WAVES);   // ~16 blocks per wave: the FFT of the taps costs 1/33
     if (groups < 1) groups = 1;
     dim3 grid((unsigned)groups, (unsigned)nblocks);
     const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE);
