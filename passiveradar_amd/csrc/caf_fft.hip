@@ -58,6 +58,7 @@ struct CafFftArgs {
     int32_t piece;     // B = 1024 - range_bins
 };
 
+template <bool HAS_WIN>
 __global__ __launch_bounds__(64 * CAFF_WAVES, 2) void caf_fft_kernel(CafFftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
@@ -67,13 +68,16 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, 2) void caf_fft_kernel(CafFftArgs 
 
     const FftLane f = fft_lane_setup();
     const int lane = f.lane;
-    const int64_t j = (int64_t)blockIdx.x * CAFF_WAVES + (threadIdx.x >> 6);
+    // the wave index is wave-uniform: say so, or every buffer descriptor derived from it lands in
+    // VGPRs and each load becomes a waterfall loop
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t j = (int64_t)blockIdx.x * CAFF_WAVES + wave_id;
     const int b = blockIdx.y;
     if (j >= a.s.freq_bins) return;
     const float2* __restrict__ ref = a.s.ref + (int64_t)b * a.s.frame_stride;
     const float2* __restrict__ srv = a.s.srv + (int64_t)b * a.s.frame_stride;
     const float* __restrict__ win = a.s.window;
-    // frame-relative 32-bit offsets everywhere (n < 2^31): uniform 64-bit base + 32-bit lane offset
+    // frame-relative 32-bit arithmetic (n < 2^31); all of it is wave-uniform (SGPRs)
     const int N = (int)a.s.n, NV = (int)a.s.n_valid;
     const int R = a.s.range_bins;
     const int B = a.piece;
@@ -87,23 +91,27 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, 2) void caf_fft_kernel(CafFftArgs 
 #pragma unroll
     for (int m = 0; m < 16; ++m) acc[m] = make_float2(0.f, 0.f);
 
-    // Software pipeline: the loads of a piece are issued one FFT ahead of their use and are
-    // branch-free (clamped address + select), so the loop body is one straight-line block:
+    // Software pipeline: the loads of a piece are issued one FFT ahead of their use.  They are raw
+    // buffer loads: the descriptor's num_records encodes "samples of this piece that exist", so the
+    // zero padding of U, the ragged last piece, n_valid < n and the prefetch past the last piece
+    // all come back as zeros from the hardware range check -- no per-lane compare / select / 64-bit
+    // address arithmetic in the loop:
     //   [u(i) resident]  issue v(i)  | FFT u(i) |  issue u(i+1), w(i+1)  | FFT v(i) | acc
+    const unsigned vo8 = (unsigned)lane * 8u, vo4 = (unsigned)lane * 4u;
     float2 un[16];
     float wn[16];
+    auto clampu = [](int x) { return x < 0 ? 0u : (unsigned)x; };
     auto issue_u = [&](int n0) {
         const int rem = hi - n0 + 1;
-        const int cnt = rem < B ? (rem < 0 ? 0 : rem) : B;
+        int cnt = rem < B ? rem : B;
+        if (NV - n0 < cnt) cnt = NV - n0;
+        const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + n0, clampu(cnt) * 8u);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int idx = 64 * r + lane;
-            const int off = n0 + idx;
-            const bool ok = idx < cnt && off < NV;
-            const int oc = ok ? off : 0;
-            un[r] = ref[oc];
-            wn[r] = win ? win[oc] : 1.0f;
-            if (!ok) wn[r] = 0.f;
+        for (int r = 0; r < 16; ++r) un[r] = prc_buf_load_c64(ru, vo8, 512u * r);
+        if (HAS_WIN) {
+            const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + n0, clampu(cnt) * 4u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wn[r] = prc_buf_load_f32(rw, vo4, 256u * r);
         }
     };
     issue_u(lo);
@@ -112,24 +120,32 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, 2) void caf_fft_kernel(CafFftArgs 
         const int cnt = rem < B ? rem : B;
         float2 u[16], v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = make_float2(un[r].x * wn[r], un[r].y * wn[r]);
-        bool okv[16];
+        for (int r = 0; r < 16; ++r)
+            u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
+        // srv slots [0, cnt+R): the part before the end of the frame, then (last segment only) the
+        // part that wraps around to the start of the frame (np.roll, :82)
+        int c1 = cnt + R;
+        if (N - n0 < c1) c1 = N - n0;
+        if (NV - n0 < c1) c1 = NV - n0;
+        const __amdgpu_buffer_rsrc_t rv = prc_rsrc(srv + n0, clampu(c1) * 8u);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int idx = 64 * r + lane;
-            int off = n0 + idx;
-            if (off >= N) off -= N;                     // circular wrap of srv inside the frame (:82)
-            okv[r] = idx < cnt + R && off < NV;
-            v[r] = srv[okv[r] ? off : 0];
+        for (int r = 0; r < 16; ++r) v[r] = prc_buf_load_c64(rv, vo8, 512u * r);
+        const int over = n0 + cnt + R - N;              // slots that wrapped (wave-uniform, rare)
+        if (over > 0) {
+            const __amdgpu_buffer_rsrc_t rw2 = prc_rsrc(srv, clampu(over < NV ? over : NV) * 8u);
+            const unsigned voff = vo8 - (unsigned)(N - n0) * 8u;   // lanes before the wrap: huge offset -> 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float2 w2 = prc_buf_load_c64(rw2, voff + 512u * r, 0u);
+                v[r].x += w2.x;
+                v[r].y += w2.y;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         fft1024_fwd(u, tile, tab, f);
         __builtin_amdgcn_sched_barrier(0);
-        issue_u(n0 + B);                                // past the last piece: cnt = 0 -> all lanes read ref[0], masked
+        issue_u(n0 + B);                                // past the last piece: zero records -> zeros
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (!okv[r]) v[r] = make_float2(0.f, 0.f);
         fft1024_fwd(v, tile, tab, f);
 #pragma unroll
         for (int m = 0; m < 16; ++m) cmac_conj_a(acc[m], u[m], v[m]);
@@ -178,7 +194,10 @@ int caf_launch_fft(const CafSegArgs& s, int nframes, hipStream_t stream) {
     if (rc) return rc;
     dim3 grid((unsigned)((s.freq_bins + CAFF_WAVES - 1) / CAFF_WAVES), (unsigned)nframes);
     const size_t lds = sizeof(float2) * (FFTW_TABLE + CAFF_WAVES * FFTW_TILE);
-    hipLaunchKernelGGL(caf_fft_kernel, grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+    if (s.window)
+        hipLaunchKernelGGL(caf_fft_kernel<true>, grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+    else
+        hipLaunchKernelGGL(caf_fft_kernel<false>, grid, dim3(64 * CAFF_WAVES), lds, stream, a);
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }

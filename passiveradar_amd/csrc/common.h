@@ -78,6 +78,28 @@ __device__ __forceinline__ double2 zdiv(double2 a, double2 b) {
     return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
 }
 
+// ---- raw buffer loads: uniform 64-bit base + num_records in SGPRs, one 32-bit lane offset in a
+// VGPR, and the hardware range check returns 0 for every lane beyond num_records -- so zero
+// padding, ragged tails and "past the end" prefetches cost no compare/select/address VALU at all.
+typedef unsigned int prc_v2u __attribute__((ext_vector_type(2)));
+// base and bytes MUST be wave-uniform; the readfirstlane pins them in SGPRs (hipcc otherwise keeps
+// min/max chains in VGPRs and wraps every load in a waterfall loop).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t prc_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane(bytes);
+    void* q = (void*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, (int)nb, 0x00020000);
+}
+__device__ __forceinline__ float2 prc_buf_load_c64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const prc_v2u x = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+    return make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
+}
+__device__ __forceinline__ float prc_buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
 // The reference's frequency_shift keeps the sample index in complex64, so the phase ramp is
 // float32:  ph = fl32(fl32(a32 * n) * rcp32)  (signal_utils.py:24-27; NumPy complex/real
 // division multiplies by the float32 reciprocal).  No FMA contraction is possible here

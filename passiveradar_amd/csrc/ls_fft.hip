@@ -235,6 +235,208 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fir_fft_kernel(LsFftArgs
     }
 }
 
+// ---- linear-boundary fast paths (LS_Filter_Toeplitz / LS_Filter_Multiple) -----------------------
+// Same arithmetic as the two kernels above for circular == 0, with every global access turned into
+// a raw buffer load/store: base + num_records live in SGPRs and the hardware range check supplies
+// the zeros (padding of U, extension past the block end, the block start of the first FIR block,
+// the prefetch past the last piece), so the loop bodies carry no per-lane compares, selects or
+// 64-bit address arithmetic.  The <= peek samples whose source index wrapped around the block end
+// (np.roll at :139) are patched in by a wave-uniform, rarely taken branch with their own phase.
+__device__ __forceinline__ unsigned lsf_clampu(int x) { return x < 0 ? 0u : (unsigned)x; }
+
+template <bool AUTO>
+__global__ __launch_bounds__(64 * LSF_WAVES, AUTO ? 1 : 2) void ls_corr_fft_lin_kernel(LsFftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* tab = reinterpret_cast<float2*>(smem_raw);
+    float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
+    fft_load_tables(tab, a.tab);
+    __syncthreads();
+    const FftLane f = fft_lane_setup();
+    const int lane = f.lane;
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wg = blockIdx.x * LSF_WAVES + wave_id;
+    const int nwaves = gridDim.x * LSF_WAVES;
+    const int b = blockIdx.y;
+    const float2* __restrict__ ref = a.ref + (int64_t)b * a.ref_stride;
+    const float2* __restrict__ srv = a.srv + (int64_t)b * a.srv_stride;
+    const int n = (int)a.n;
+    const int T = a.T, B = a.piece, ext = T - 1, peek = a.peek;
+    const unsigned vo8 = (unsigned)lane * 8u;
+
+    float2 wrr[16], wrs[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { wrr[m] = make_float2(0.f, 0.f); wrs[m] = make_float2(0.f, 0.f); }
+
+    const int npieces = (n + B - 1) / B;
+    float2 en[16];
+    float2 ebase = make_float2(1.f, 0.f);
+    auto issue_e = [&](int p) {
+        const bool live = p < npieces;
+        const int m0 = live ? p * B : 0;
+        const int rem = n - m0;
+        const int cnt = live ? (rem < B ? rem : B) : 0;
+        int ce = live ? cnt + ext : 0;                        // slots wanted
+        if (n - peek - m0 < ce) ce = n - peek - m0;           // ... whose source m+peek does not wrap
+        const __amdgpu_buffer_rsrc_t re = prc_rsrc(ref + m0 + peek, lsf_clampu(ce) * 8u);
+        if (a.rot) ebase = phase_rot(a.pr, (int64_t)m0 + lane + peek);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) en[r] = prc_buf_load_c64(re, vo8, 512u * r);
+    };
+    issue_e(wg);
+    for (int p = wg; p < npieces; p += nwaves) {
+        const int m0 = p * B;
+        const int rem = n - m0;
+        const int cnt = rem < B ? rem : B;
+        float2 u[16], v[16], sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = a.rot ? cmul(en[r], cmul(ebase, a.step[r])) : en[r];
+        // slots m in [n-peek, n): source wrapped to ref[0..peek), phase ramp restarted (rare)
+        const int wstart = n - peek - m0;                     // first wrapped slot of this piece
+        int want = cnt + ext;
+        if (n - m0 < want) want = n - m0;                     // linear correlation: nothing beyond the block
+        if (peek > 0 && want > wstart) {
+            const __amdgpu_buffer_rsrc_t rw = prc_rsrc(ref, lsf_clampu(want - wstart) * 8u);
+            const unsigned voff = vo8 - (unsigned)wstart * 8u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float2 w = prc_buf_load_c64(rw, voff + 512u * r, 0u);
+                if (a.rot) w = cmul(w, small_rot(a.theta32 * (float)(64 * r + lane - wstart)));
+                v[r].x += w.x;
+                v[r].y += w.y;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = (64 * r + lane) < cnt ? v[r] : make_float2(0.f, 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+        fft1024_fwd(u, tile, tab, f);
+        __builtin_amdgcn_sched_barrier(0);
+        {   // surveillance slots of this piece (consumed one or two FFTs later)
+            const __amdgpu_buffer_rsrc_t rs = prc_rsrc(srv + m0, lsf_clampu(want) * 8u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = prc_buf_load_c64(rs, vo8, 512u * r);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (AUTO) {
+            fft1024_fwd(v, tile, tab, f);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) cmac_conj_a(wrr[m], u[m], v[m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_e(p + nwaves);
+        __builtin_amdgcn_sched_barrier(0);
+        fft1024_fwd(sv, tile, tab, f);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) cmac_conj_a(wrs[m], u[m], sv[m]);
+    }
+    if (AUTO) fft1024_inv(wrr, tile, tab, f);
+    fft1024_inv(wrs, tile, tab, f);
+    float2* __restrict__ part = a.partial + ((int64_t)b * nwaves + wg) * 2 * T;
+    const float sc = 1.0f / 1024.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lag = 64 * r + lane;
+        if (lag < T) {
+            if (AUTO) part[lag] = make_float2(wrr[r].x * sc, -wrr[r].y * sc);
+            part[T + lag] = make_float2(wrs[r].x * sc, -wrs[r].y * sc);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fir_fft_lin_kernel(LsFftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* tab = reinterpret_cast<float2*>(smem_raw);
+    float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
+    fft_load_tables(tab, a.tab);
+    __syncthreads();
+    const FftLane f = fft_lane_setup();
+    const int lane = f.lane;
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wg = blockIdx.x * LSF_WAVES + wave_id;
+    const int nwaves = gridDim.x * LSF_WAVES;
+    const int b = blockIdx.y;
+    const float2* __restrict__ ref = a.ref + (int64_t)b * a.ref_stride;
+    const float2* __restrict__ srv = a.srv + (int64_t)b * a.srv_stride;
+    float2* __restrict__ out = a.out + (int64_t)b * a.out_stride;
+    const double2* __restrict__ taps = a.taps + (int64_t)b * a.T;
+    const int n = (int)a.n;
+    const int T = a.T, B = a.piece, ext = T - 1, peek = a.peek;
+    const unsigned vo8 = (unsigned)lane * 8u;
+
+    float2 h[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int idx = 64 * r + lane;
+        const double2 t = taps[idx < T ? idx : 0];
+        h[r] = idx < T ? make_float2((float)t.x, (float)t.y) : make_float2(0.f, 0.f);
+    }
+    fft1024_fwd(h, tile, tab, f);
+    const float sc = 1.0f / 1024.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { h[r].x *= sc; h[r].y *= sc; }
+
+    const int nblocks = (n + B - 1) / B;
+    // unwrapped reference: slot idx of block p <-> ref[peek + mstart + idx], valid for 0 <= mstart+idx < n-peek:
+    // one descriptor for the whole block (base ref+peek), the lane offset carries mstart (negative
+    // for the first block: wraps to a huge unsigned offset -> out of range -> 0)
+    const __amdgpu_buffer_rsrc_t rx = prc_rsrc(ref + peek, lsf_clampu(n - peek) * 8u);
+    float2 xn[16];
+    float2 xbase = make_float2(1.f, 0.f);
+    auto issue_x = [&](int p) {
+        const bool live = p < nblocks;
+        const int mstart = (live ? p * B : n) - ext;          // dead prefetch: everything out of range
+        if (a.rot) xbase = phase_rot(a.pr, (int64_t)mstart + lane + peek);
+        const unsigned voff = vo8 + (unsigned)mstart * 8u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rx, voff + 512u * r, 0u);
+    };
+    issue_x(wg);
+    for (int p = wg; p < nblocks; p += nwaves) {
+        const int n0 = p * B;
+        const int mstart = n0 - ext;
+        float2 x[16], sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = a.rot ? cmul(xn[r], cmul(xbase, a.step[r])) : xn[r];
+        const int wstart = n - peek - mstart;                 // first slot whose source wrapped (rare)
+        if (peek > 0 && wstart < FFTW_P) {
+            int cw = FFTW_P - wstart;
+            if (cw > peek) cw = peek;
+            const __amdgpu_buffer_rsrc_t rw = prc_rsrc(ref, lsf_clampu(cw) * 8u);
+            const unsigned voff = vo8 - (unsigned)wstart * 8u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float2 w = prc_buf_load_c64(rw, voff + 512u * r, 0u);
+                if (a.rot) w = cmul(w, small_rot(a.theta32 * (float)(64 * r + lane - wstart)));
+                x[r].x += w.x;
+                x[r].y += w.y;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fft1024_fwd(x, tile, tab, f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = cmul(x[r], h[r]);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(p + nwaves);
+        // outputs nn = n0 + idx - ext for idx >= ext: lane offset carries -ext (idx < ext -> out of range)
+        const int cnt = (n - n0) < B ? (n - n0) : B;
+        const unsigned vout = vo8 - (unsigned)ext * 8u;
+        {
+            const __amdgpu_buffer_rsrc_t rs = prc_rsrc(srv + n0, lsf_clampu(cnt) * 8u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = prc_buf_load_c64(rs, vout + 512u * r, 0u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fft1024_inv(x, tile, tab, f);
+        const __amdgpu_buffer_rsrc_t ro = prc_rsrc(out + n0, lsf_clampu(cnt) * 8u);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            prc_v2u d;
+            d.x = __float_as_uint(sv[r].x - x[r].x);
+            d.y = __float_as_uint(sv[r].y - x[r].y);
+            __builtin_amdgcn_raw_buffer_store_b64(d, ro, (int)(vout + 512u * r), 0, 0);
+        }
+    }
+}
+
 bool ls_fft_supported(int T) { return T >= 2 && T - 1 <= 768; }
 
 int ls_fft_waves_per_block(int64_t n, int T) {
@@ -264,7 +466,12 @@ int ls_launch_corr_fft(LsFftArgs a, double theta, int waves_per_block, int nbloc
     if (rc) return rc;
     dim3 grid((unsigned)(waves_per_block / LSF_WAVES), (unsigned)nblocks);
     const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE);
-    if (with_autocorr)
+    if (!a.circular) {
+        if (with_autocorr)
+            hipLaunchKernelGGL(ls_corr_fft_lin_kernel<true>, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+        else
+            hipLaunchKernelGGL(ls_corr_fft_lin_kernel<false>, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    } else if (with_autocorr)
         hipLaunchKernelGGL(ls_corr_fft_kernel<true>, grid, dim3(64 * LSF_WAVES), lds, stream, a);
     else
         hipLaunchKernelGGL(ls_corr_fft_kernel<false>, grid, dim3(64 * LSF_WAVES), lds, stream, a);
@@ -282,7 +489,10 @@ int ls_launch_fir_fft(LsFftArgs a, double theta, int nblocks, hipStream_t stream
     if (groups < 1) groups = 1;
     dim3 grid((unsigned)groups, (unsigned)nblocks);
     const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE);
-    hipLaunchKernelGGL(ls_fir_fft_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    if (!a.circular)
+        hipLaunchKernelGGL(ls_fir_fft_lin_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    else
+        hipLaunchKernelGGL(ls_fir_fft_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }
