@@ -55,10 +55,14 @@ int fftw_device_tables(const float2** out) {
 struct CafFftArgs {
     CafSegArgs s;
     const float2* tab;
-    int32_t piece;     // B = 1024 - range_bins
+    int32_t piece;     // B = 1025 - lags_per_block samples of ref per FFT
+    int32_t lagblk;    // lags per block (<= 769)
+    int32_t nlagblk;   // number of lag blocks covering 0..range_bins
 };
 
-template <bool HAS_WIN>
+// NLB lag blocks are accumulated per pass over the segment (U = FFT(w*ref piece) is shared by
+// them; V_l = FFT(srv piece shifted by l*lagblk)); more lag blocks than NLB repeat the pass.
+template <bool HAS_WIN, int NLB>
 __global__ __launch_bounds__(64 * CAFF_WAVES, 2) void caf_fft_kernel(CafFftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
@@ -80,83 +84,102 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, 2) void caf_fft_kernel(CafFftArgs 
     // frame-relative 32-bit arithmetic (n < 2^31); all of it is wave-uniform (SGPRs)
     const int N = (int)a.s.n, NV = (int)a.s.n_valid;
     const int R = a.s.range_bins;
-    const int B = a.piece;
+    const int B = a.piece, LB = a.lagblk;
 
     const int64_t n_hi64 = j * a.s.q + a.s.half;
     const int64_t n_lo64 = n_hi64 - (a.s.ntaps - 1);
     const int lo = n_lo64 < 0 ? 0 : (int)n_lo64;
     const int hi = n_hi64 > N - 1 ? N - 1 : (int)n_hi64;
-
-    float2 acc[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) acc[m] = make_float2(0.f, 0.f);
-
-    // Software pipeline: the loads of a piece are issued one FFT ahead of their use.  They are raw
-    // buffer loads: the descriptor's num_records encodes "samples of this piece that exist", so the
-    // zero padding of U, the ragged last piece, n_valid < n and the prefetch past the last piece
-    // all come back as zeros from the hardware range check -- no per-lane compare / select / 64-bit
-    // address arithmetic in the loop:
-    //   [u(i) resident]  issue v(i)  | FFT u(i) |  issue u(i+1), w(i+1)  | FFT v(i) | acc
     const unsigned vo8 = (unsigned)lane * 8u, vo4 = (unsigned)lane * 4u;
-    float2 un[16];
-    float wn[16];
     auto clampu = [](int x) { return x < 0 ? 0u : (unsigned)x; };
-    auto issue_u = [&](int n0) {
-        const int rem = hi - n0 + 1;
-        int cnt = rem < B ? rem : B;
-        if (NV - n0 < cnt) cnt = NV - n0;
-        const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + n0, clampu(cnt) * 8u);
+    float2* __restrict__ yrow = a.s.y + ((int64_t)b * a.s.freq_bins + j) * (R + 1);
+    const float sc = 1.0f / 1024.0f;
+
+    for (int lb0 = 0; lb0 < a.nlagblk; lb0 += NLB) {
+        float2 acc[NLB][16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) un[r] = prc_buf_load_c64(ru, vo8, 512u * r);
-        if (HAS_WIN) {
-            const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + n0, clampu(cnt) * 4u);
+        for (int l = 0; l < NLB; ++l)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) wn[r] = prc_buf_load_f32(rw, vo4, 256u * r);
-        }
-    };
-    issue_u(lo);
-    for (int n0 = lo; n0 <= hi; n0 += B) {
-        const int rem = hi - n0 + 1;
-        const int cnt = rem < B ? rem : B;
-        float2 u[16], v[16];
+            for (int m = 0; m < 16; ++m) acc[l][m] = make_float2(0.f, 0.f);
+
+        // Software pipeline: the loads of a piece are issued one FFT ahead of their use.  They are
+        // raw buffer loads: the descriptor's num_records encodes "samples of this piece that
+        // exist", so the zero padding of U, the ragged last piece, n_valid < n and the prefetch past
+        // the last piece all come back as zeros from the hardware range check:
+        //   [u(i) resident] issue v0(i) | FFT u(i) | issue v1(i) / u(i+1) | FFT v0 | ... | acc
+        float2 un[16];
+        float wn[16];
+        auto issue_u = [&](int n0) {
+            const int rem = hi - n0 + 1;
+            int cnt = rem < B ? rem : B;
+            if (NV - n0 < cnt) cnt = NV - n0;
+            const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + n0, clampu(cnt) * 8u);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
-        // srv slots [0, cnt+R): the part before the end of the frame, then (last segment only) the
-        // part that wraps around to the start of the frame (np.roll, :82)
-        int c1 = cnt + R;
-        if (N - n0 < c1) c1 = N - n0;
-        if (NV - n0 < c1) c1 = NV - n0;
-        const __amdgpu_buffer_rsrc_t rv = prc_rsrc(srv + n0, clampu(c1) * 8u);
+            for (int r = 0; r < 16; ++r) un[r] = prc_buf_load_c64(ru, vo8, 512u * r);
+            if (HAS_WIN) {
+                const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + n0, clampu(cnt) * 4u);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = prc_buf_load_c64(rv, vo8, 512u * r);
-        const int over = n0 + cnt + R - N;              // slots that wrapped (wave-uniform, rare)
-        if (over > 0) {
-            const __amdgpu_buffer_rsrc_t rw2 = prc_rsrc(srv, clampu(over < NV ? over : NV) * 8u);
-            const unsigned voff = vo8 - (unsigned)(N - n0) * 8u;   // lanes before the wrap: huge offset -> 0
+                for (int r = 0; r < 16; ++r) wn[r] = prc_buf_load_f32(rw, vo4, 256u * r);
+            }
+        };
+        // srv slots [0, cnt+LB-1) of lag block lb: frame offsets start .. with circular wrap (:82)
+        auto issue_v = [&](float2 (&v)[16], int n0, int cnt, int lb) {
+            int start = n0 + lb * LB;
+            if (start >= N) start -= N;
+            const int want = cnt + LB - 1;
+            int c1 = want;
+            if (N - start < c1) c1 = N - start;
+            if (NV - start < c1) c1 = NV - start;
+            const __amdgpu_buffer_rsrc_t rv = prc_rsrc(srv + start, clampu(c1) * 8u);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float2 w2 = prc_buf_load_c64(rw2, voff + 512u * r, 0u);
-                v[r].x += w2.x;
-                v[r].y += w2.y;
+            for (int r = 0; r < 16; ++r) v[r] = prc_buf_load_c64(rv, vo8, 512u * r);
+            const int over = start + want - N;              // slots that wrapped (wave-uniform, rare)
+            if (over > 0) {
+                const __amdgpu_buffer_rsrc_t rw2 = prc_rsrc(srv, clampu(over < NV ? over : NV) * 8u);
+                const unsigned voff = vo8 - (unsigned)(N - start) * 8u;   // lanes before the wrap: out of range
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float2 w2 = prc_buf_load_c64(rw2, voff + 512u * r, 0u);
+                    v[r].x += w2.x;
+                    v[r].y += w2.y;
+                }
+            }
+        };
+        issue_u(lo);
+        for (int n0 = lo; n0 <= hi; n0 += B) {
+            const int rem = hi - n0 + 1;
+            const int cnt = rem < B ? rem : B;
+            float2 u[16], v[NLB][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
+            issue_v(v[0], n0, cnt, lb0);
+            __builtin_amdgcn_sched_barrier(0);
+            fft1024_fwd(u, tile, tab, f);
+#pragma unroll
+            for (int l = 0; l < NLB; ++l) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (l + 1 < NLB)
+                    issue_v(v[l + 1 < NLB ? l + 1 : 0], n0, cnt, lb0 + l + 1);
+                else
+                    issue_u(n0 + B);                        // past the last piece: zero records -> zeros
+                __builtin_amdgcn_sched_barrier(0);
+                fft1024_fwd(v[l], tile, tab, f);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) cmac_conj_a(acc[l][m], u[m], v[l][m]);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        fft1024_fwd(u, tile, tab, f);
-        __builtin_amdgcn_sched_barrier(0);
-        issue_u(n0 + B);                                // past the last piece: zero records -> zeros
-        __builtin_amdgcn_sched_barrier(0);
-        fft1024_fwd(v, tile, tab, f);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) cmac_conj_a(acc[m], u[m], v[m]);
-    }
-    fft1024_inv(acc, tile, tab, f);
-    const float sc = 1.0f / 1024.0f;
-    float2* __restrict__ yrow = a.s.y + ((int64_t)b * a.s.freq_bins + j) * (R + 1);
+        for (int l = 0; l < NLB; ++l) {
+            fft1024_inv(acc[l], tile, tab, f);
+            const int L0 = (lb0 + l) * LB;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int lag = 64 * r + lane;
-        if (lag <= R) yrow[R - lag] = make_float2(acc[r].x * sc, -acc[r].y * sc);
+            for (int r = 0; r < 16; ++r) {
+                const int within = 64 * r + lane;
+                const int lag = L0 + within;
+                if (within < LB && lag <= R) yrow[R - lag] = make_float2(acc[l][r].x * sc, -acc[l][r].y * sc);
+            }
+        }
     }
 }
 
@@ -180,24 +203,51 @@ __global__ __launch_bounds__(256) void transpose_jk_kj_kernel(const float2* __re
     }
 }
 
+// Lag blocking: nlb blocks of LB = ceil((R+1)/nlb) lags, pieces of B = 1025-LB samples.  One pass
+// over a segment costs pieces*(1+NLB) forward FFTs (+NLB inverse); pick the cheapest split.
+static void caf_fft_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out) {
+    double best = 1e300;
+    int best_nlb = 1, best_lb = range_bins + 1;
+    for (int nlb = 1; nlb <= 64; ++nlb) {
+        const int lb = (range_bins + nlb) / nlb;             // ceil((R+1)/nlb)
+        if (lb > 769) continue;
+        const int Bp = FFTW_P + 1 - lb;
+        const double pieces = (double)((q1 + Bp - 1) / Bp);
+        const int passes = (nlb + 1) / 2;                      // NLB = 2 per pass when nlb > 1
+        const double cost = nlb == 1 ? pieces * 2 + 1 : passes * pieces * 1.0 + pieces * nlb + nlb;
+        if (cost < best) { best = cost; best_nlb = nlb; best_lb = lb; }
+        if (lb <= 2) break;
+    }
+    *nlb_out = best_nlb;
+    *lb_out = best_lb;
+}
+
 bool caf_fft_supported(int64_t n, int range_bins, int freq_bins, int boxcar) {
     (void)freq_bins;
     // n >= 2048 keeps a piece's 1024 slots from wrapping around the frame more than once
-    return boxcar && range_bins >= 1 && range_bins <= 768 && n >= 2048;
+    return boxcar && range_bins >= 1 && n >= 2048 && range_bins < n / 2;
 }
 
 int caf_launch_fft(const CafSegArgs& s, int nframes, hipStream_t stream) {
     CafFftArgs a;
     a.s = s;
-    a.piece = FFTW_P - s.range_bins;
+    caf_fft_blocking(s.ntaps, s.range_bins, &a.nlagblk, &a.lagblk);
+    a.piece = FFTW_P + 1 - a.lagblk;
     int rc = fftw_device_tables(&a.tab);
     if (rc) return rc;
     dim3 grid((unsigned)((s.freq_bins + CAFF_WAVES - 1) / CAFF_WAVES), (unsigned)nframes);
     const size_t lds = sizeof(float2) * (FFTW_TABLE + CAFF_WAVES * FFTW_TILE);
-    if (s.window)
-        hipLaunchKernelGGL(caf_fft_kernel<true>, grid, dim3(64 * CAFF_WAVES), lds, stream, a);
-    else
-        hipLaunchKernelGGL(caf_fft_kernel<false>, grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+    if (a.nlagblk == 1) {
+        if (s.window)
+            hipLaunchKernelGGL((caf_fft_kernel<true, 1>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+        else
+            hipLaunchKernelGGL((caf_fft_kernel<false, 1>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+    } else {
+        if (s.window)
+            hipLaunchKernelGGL((caf_fft_kernel<true, 2>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+        else
+            hipLaunchKernelGGL((caf_fft_kernel<false, 2>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+    }
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }

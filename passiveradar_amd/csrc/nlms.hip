@@ -21,10 +21,29 @@ struct NlmsArgs {
     float mu;
 };
 
+// All-lanes sum by DPP (no LDS crossbar): xor-1 / xor-2 inside quads, half-row mirror, row mirror
+// -> every row of 16 lanes holds its row sum; the four row sums are read with v_readlane.
+__device__ __forceinline__ float dpp_f(float x, const int which) {
+    const int i = __float_as_int(x);
+    int r;
+    switch (which) {
+        case 0: r = __builtin_amdgcn_mov_dpp(i, 0xB1, 0xF, 0xF, true); break;    // quad_perm [1,0,3,2]
+        case 1: r = __builtin_amdgcn_mov_dpp(i, 0x4E, 0xF, 0xF, true); break;    // quad_perm [2,3,0,1]
+        case 2: r = __builtin_amdgcn_mov_dpp(i, 0x141, 0xF, 0xF, true); break;   // row_half_mirror
+        default: r = __builtin_amdgcn_mov_dpp(i, 0x140, 0xF, 0xF, true); break;  // row_mirror
+    }
+    return __int_as_float(r);
+}
 __device__ __forceinline__ float wave_allsum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_f(v, 0);
+    v += dpp_f(v, 1);
+    v += dpp_f(v, 2);
+    v += dpp_f(v, 3);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
 }
 
 template <int TPL>
@@ -63,30 +82,51 @@ __global__ __launch_bounds__(64) void nlms_kernel(NlmsArgs a) {
         }
         for (int x = lane; x < cnt; x += 64) D[x] = srv[k0 + x + a.L];
         __syncthreads();
-        for (int kk = 0; kk < cnt; ++kk) {
-            float2 u[TPL];
-            float yr = 0.f, yi = 0.f, en = 0.f;
+        // u^H u is summed exactly at the start of every staged window and then slid:
+        //   E(k+1) = E(k) + |ref[T+k+1]|^2 - |ref[k+1]|^2      (window element kk+WIN enters, kk+WIN-T leaves)
+        float energy;
+        {
+            float e0 = 0.f;
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) {
+                const int i = lane + 64 * t;
+                const float2 v = Rw[WIN - 1 - i];
+                if (i < T) e0 = fmaf(v.x, v.x, fmaf(v.y, v.y, e0));
+            }
+            energy = wave_allsum(e0);
+        }
+        // One step: dot (registers), two DPP reductions, AXPY.  The sliding window of the NEXT step
+        // is fetched from LDS while this step reduces (ua/ub swap roles, loop unrolled by two), so
+        // the only latency left on the critical path is the reduction itself.
+        auto fetch = [&](float2 (&u)[TPL], int kk) {
 #pragma unroll
             for (int t = 0; t < TPL; ++t) {
                 const int i = lane + 64 * t;
                 float2 v = Rw[kk + WIN - 1 - i];
-                if (i >= T) v = make_float2(0.f, 0.f);
+                if (t == TPL - 1 && i >= T) v = make_float2(0.f, 0.f);   // only the last group can overhang T
                 u[t] = v;
-                // conj(w) * u
-                yr = fmaf(w[t].x, v.x, yr);
-                yr = fmaf(w[t].y, v.y, yr);
-                yi = fmaf(w[t].x, v.y, yi);
-                yi = fmaf(-w[t].y, v.x, yi);
-                en = fmaf(v.x, v.x, en);
-                en = fmaf(v.y, v.y, en);
             }
+        };
+        auto step = [&](const float2 (&u)[TPL], float2 (&unext)[TPL], int kk) {
+            float yr = 0.f, yi = 0.f;
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) {          // conj(w) * u
+                yr = fmaf(w[t].x, u[t].x, yr);
+                yr = fmaf(w[t].y, u[t].y, yr);
+                yi = fmaf(w[t].x, u[t].y, yi);
+                yi = fmaf(-w[t].y, u[t].x, yi);
+            }
+            fetch(unext, kk + 1);                    // independent of this step's result
             yr = wave_allsum(yr);
             yi = wave_allsum(yi);
-            en = wave_allsum(en);
+            const float en = energy;
+            {   // slide the energy to the next step (wave-uniform LDS reads, broadcast)
+                const float2 vin = Rw[kk + WIN], vout = Rw[kk + WIN - T];
+                energy += (vin.x * vin.x + vin.y * vin.y) - (vout.x * vout.x + vout.y * vout.y);
+            }
             const float2 d = D[kk];
             const float er = d.x - yr, ei = d.y - yi;
-            // coefficient mu * conj(e) / (u^H u)
-            const float s = a.mu / en;
+            const float s = a.mu / en;               // coefficient mu * conj(e) / (u^H u)
             const float cr = er * s, ci = -ei * s;
 #pragma unroll
             for (int t = 0; t < TPL; ++t) {
@@ -96,7 +136,15 @@ __global__ __launch_bounds__(64) void nlms_kernel(NlmsArgs a) {
                 w[t].y = fmaf(ci, u[t].x, w[t].y);
             }
             if (lane == 0) D[kk] = make_float2(er, ei);
+        };
+        float2 ua[TPL], ub[TPL];
+        fetch(ua, 0);
+        int kk = 0;
+        for (; kk + 2 <= cnt; kk += 2) {
+            step(ua, ub, kk);
+            step(ub, ua, kk + 1);
         }
+        if (kk < cnt) step(ua, ub, kk);
         __syncthreads();
         for (int x = lane; x < cnt; x += 64) out[a.L + k0 + x] = D[x];
     }
