@@ -196,16 +196,18 @@ def main():
             acc = np.zeros(3)
             for _ in range(reps):
                 be.clean(ref_pad, srv_pad, B)
-                m0, m1, m2, k = be.ls.get_profile()
-                acc += (m0, m1, m2)
+                ms3, k3 = be.ls.get_profile()
+                acc += ms3
             be.ls.set_profiling(False)
-            acc /= reps * k
+            acc /= reps
+            nb = B if len(be.ls_lanes) < 2 else be.ls_per     # blocks behind one launch
             T = R + 10
-            nblk = -(-C // 4096)
-            kt["ls_correlate"] = {"ms": acc[0], "launches_per_step": k, "bytes": B * 16.0 * C}
-            kt["ls_levinson"] = {"ms": acc[1], "launches_per_step": k,
-                                 "bytes": B * (nblk * 2 * T * 8.0 + T * 16.0)}
-            kt["ls_fir_subtract"] = {"ms": acc[2], "launches_per_step": k, "bytes": B * 24.0 * C}
+            fused = k3[0] == 1 and k3[2] > 1                   # cached-spectrum chain: corr(i+1) inside FIR(i)
+            kt["ls_correlate"] = {"ms": acc[0] / k3[0], "launches_per_step": k3[0], "bytes": nb * 16.0 * C}
+            kt["ls_solve"] = {"ms": acc[1] / k3[1], "launches_per_step": k3[1],
+                              "bytes": nb * (T * T * 16.0 + 64 * 2 * T * 8.0)}
+            fir_bytes = 24.0 * C + (16.0 * C * (k3[2] - 1) / k3[2] if fused else 0.0)
+            kt["ls_fir_subtract"] = {"ms": acc[2] / k3[2], "launches_per_step": k3[2], "bytes": nb * fir_bytes}
         elif clutter == "nlms":
             a, b = ev(), ev()
             a.record()

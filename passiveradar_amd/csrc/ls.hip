@@ -453,13 +453,17 @@ __global__ __launch_bounds__(LS_THREADS) void ls_prepare_kernel(LsPrepArgs a) {
 }
 
 struct LsSolveArgs {
-    const float2* partial;   // slot 1 = conj(cross-correlation with the current surveillance stream)
+    const float2* partial;   // slot 1 = conj( sum_n s~[n] conj(rho[n-k]) ), s~ = s e^{-j theta (n+peek)}
     const double2* c0;
     const double2* se;
     const double2* tinv;
-    double2* taps;           // [block][T]
+    const float2* ref;       // for the <= peek wrapped samples of rho
+    const float2* srv;       // current surveillance stream (input of this bin)
+    int64_t ref_stride, srv_stride;
+    double2* taps;           // [block][T]  w
+    double2* taps_t;         // [block][T]  w~[k] = w[k] e^{-j theta k}  (what the cached FIR applies)
     int64_t n;
-    int32_t nblk, T, nref;
+    int32_t nblk, T, nref, peek;
     double theta;            // rotation of this bin (effective float32 ramp slope)
 };
 
@@ -494,7 +498,22 @@ __global__ __launch_bounds__(LSS_THREADS) void ls_solve_kernel(LsSolveArgs a) {
         double sn, cs;
         sincos(a.theta * (double)k, &sn, &cs);
         const double2 D = make_double2(cs, sn);
-        const double2 rhs = make_double2(br, -bi);
+        // b_f[k] = e^{j theta k} ( B~[k] + (conj(gamma)-1) E_b[k] ),
+        // E_b[k] = sum_{m=N-peek}^{N-1-k} conj(rho[m]) s~[m+k]   (k < peek; rho[m] = ref[m+peek-N])
+        double2 eb = make_double2(0, 0);
+        if (a.theta != 0.0 && k < a.peek) {
+            const float2* rr = a.ref + (int64_t)b * a.ref_stride;
+            const float2* ss = a.srv + (int64_t)b * a.srv_stride;
+            for (int64_t m = a.n - a.peek; m + k < a.n; ++m) {
+                const float2 r = rr[m + a.peek - a.n];
+                const float2 sraw = ss[m + k];
+                double s2, c2;
+                sincos(-a.theta * (double)(m + k + a.peek), &s2, &c2);
+                const double2 st = zmul(make_double2(sraw.x, sraw.y), make_double2(c2, s2));
+                eb = zadd(eb, zmul(make_double2(r.x, -r.y), st));
+            }
+        }
+        const double2 rhs = zmul(D, zadd(make_double2(br, -bi), zmul(make_double2(gx, -gy), eb)));
         bb[k] = rhs;
         dd[k] = D;
         v[k] = zmul(zconj(D), rhs);
@@ -557,7 +576,10 @@ __global__ __launch_bounds__(LSS_THREADS) void ls_solve_kernel(LsSolveArgs a) {
         }
         __syncthreads();
     }
-    for (int k = tid; k < T; k += LSS_THREADS) a.taps[(int64_t)b * T + k] = x[k];
+    for (int k = tid; k < T; k += LSS_THREADS) {
+        a.taps[(int64_t)b * T + k] = x[k];
+        a.taps_t[(int64_t)b * T + k] = zmul(x[k], zconj(dd[k]));
+    }
 }
 
 // ---- FIR apply: out[n] = s[n] - sum_k w[k] r[n-k] ----------------------------------------
@@ -635,10 +657,13 @@ struct prc_ls_plan {
     double2* d_c0 = nullptr;
     double2* d_se = nullptr;
     double2* d_tinv = nullptr;
+    double2* d_taps_t = nullptr;   // w~ per block
+    float2* d_cache = nullptr;     // FFT(rho block) per piece, reused by every bin
     // optional per-kernel timing (bench.py roofline): events around every launch of one execute
     int profiling = 0;
     std::vector<hipEvent_t> ev;     // 4 per Doppler bin: before corr, after corr, after levinson, after fir
     int ev_bins = 0;
+    bool last_cached = false;     // the last execute ran the cached-spectrum chain
     std::mutex mtx;
 };
 
@@ -651,6 +676,8 @@ extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
     if (p->d_c0) (void)hipFree(p->d_c0);
     if (p->d_se) (void)hipFree(p->d_se);
     if (p->d_tinv) (void)hipFree(p->d_tinv);
+    if (p->d_taps_t) (void)hipFree(p->d_taps_t);
+    if (p->d_cache) (void)hipFree(p->d_cache);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
     return PRC_OK;
@@ -691,6 +718,9 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
         e = hipMalloc(&p->d_c0, sizeof(double2) * (size_t)d->max_blocks * T);
         if (e == hipSuccess) e = hipMalloc(&p->d_se, sizeof(double2) * (size_t)d->max_blocks * T);
         if (e == hipSuccess) e = hipMalloc(&p->d_tinv, sizeof(double2) * (size_t)d->max_blocks * T * T);
+        if (e == hipSuccess) e = hipMalloc(&p->d_taps_t, sizeof(double2) * (size_t)d->max_blocks * T);
+        if (e == hipSuccess)
+            e = hipMalloc(&p->d_cache, sizeof(float2) * (size_t)d->max_blocks * ls_cache_elems_per_block(d->n, T));
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)ls_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
@@ -720,6 +750,116 @@ static PhaseRamp make_ramp(double fc, double fs, double phase_offset) {
     return pr;
 }
 
+static void fill_xa(LsFftArgs& xa, prc_ls_plan* p, const void* ref, int64_t stride, const float2* cur,
+                    int64_t cur_stride, float2* dst, int64_t dst_stride, const PhaseRamp& pr) {
+    xa.ref = (const float2*)ref;  xa.ref_stride = stride;
+    xa.srv = cur;                 xa.srv_stride = cur_stride;
+    xa.out = dst;                 xa.out_stride = dst_stride;
+    xa.partial = p->d_partial;
+    xa.taps = p->d_taps;
+    xa.taps_t = p->d_taps_t;
+    xa.cache = p->d_cache;
+    xa.tab = nullptr;
+    xa.n = p->desc.n;
+    xa.T = p->T;
+    xa.peek = p->desc.peek;
+    xa.circular = p->desc.circular;
+    xa.rot = pr.enabled;
+    xa.pr = pr;
+    xa.has_next = 0;
+    xa.rot2 = 0;
+    xa.pr2 = pr;
+}
+
+// Cached-spectrum chain (LS_Filter_Multiple on long linear blocks):
+//   corr(bin 0) + cache -> prepare (Durbin + Trench, once) -> solve(0)
+//   -> [ FIR(i) fused with corr(i+1) -> solve(i+1) ] for every bin.
+static int run_cached_chain(prc_ls_plan* p, const void* ref, const void* srv, int64_t stride, void* out,
+                            int64_t out_stride, int nblocks, double sample_rate, const double* bins,
+                            int nbins, double reg, hipStream_t stream) {
+    const int T = p->T;
+    const int64_t n = p->desc.n;
+    const int RP = (T + 63) & ~63;
+    const int parts = LSS_THREADS / RP > 0 ? LSS_THREADS / RP : 1;
+    const size_t solve_lds = sizeof(double2) * ((size_t)5 * T + (size_t)parts * RP);
+    auto theta_exact = [&](int i) { return 2.0 * 3.14159265358979323846 * bins[i] / sample_rate; };
+    auto launch_solve = [&](int i, const float2* cur, int64_t cur_stride) -> int {
+        const PhaseRamp pr = make_ramp(bins[i], sample_rate, 0.0);
+        LsSolveArgs sa;
+        sa.partial = p->d_partial;  sa.c0 = p->d_c0;  sa.se = p->d_se;  sa.tinv = p->d_tinv;
+        sa.ref = (const float2*)ref;  sa.ref_stride = stride;
+        sa.srv = cur;  sa.srv_stride = cur_stride;
+        sa.taps = p->d_taps;  sa.taps_t = p->d_taps_t;
+        sa.n = n;  sa.nblk = p->nblk;  sa.T = T;  sa.peek = p->desc.peek;
+        // effective slope of the reference's float32 ramp: fl32(2 pi f) * fl32(1/Fs)
+        sa.theta = pr.enabled ? (double)pr.a32 * (double)pr.rcp32 : 0.0;
+        // one refinement squares the wrap perturbation (~ a few peek/N); two for shorter blocks
+        sa.nref = !pr.enabled ? 0 : (n >= 100000LL * (p->desc.peek > 0 ? p->desc.peek : 1) ? 1 : 2);
+        hipLaunchKernelGGL(ls_solve_kernel, dim3(nblocks), dim3(LSS_THREADS), solve_lds, stream, sa);
+        PRC_LAUNCH_CHECK();
+        return PRC_OK;
+    };
+    const float2* cur = (const float2*)srv;
+    int64_t cur_stride = stride;
+    int rc;
+    {
+        const PhaseRamp pr0 = make_ramp(bins[0], sample_rate, 0.0);
+        PRC_REQUIRE(!pr0.enabled || fabs(theta_exact(0)) * (p->desc.peek + 1) <= 0.3, PRC_EUNSUPPORTED,
+                    "prc_ls_execute: |2 pi fc/Fs| * peek too large for the FFT kernels (use method=1)");
+        LsFftArgs xa;
+        fill_xa(xa, p, ref, stride, cur, cur_stride, nullptr, 0, pr0);
+        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[0], stream));
+        rc = ls_launch_corr_cached(xa, theta_exact(0), p->fft_waves, nblocks, stream);
+        if (rc) return rc;
+        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[1], stream));
+        LsPrepArgs pa;
+        pa.partial = p->d_partial;  pa.ref = (const float2*)ref;  pa.ref_stride = stride;
+        pa.n = n;  pa.nblk = p->nblk;  pa.T = T;  pa.peek = p->desc.peek;  pa.reg = reg;
+        pa.theta0 = 0.0;                // the chain correlates the unrotated reference
+        pa.c0 = p->d_c0;  pa.se = p->d_se;  pa.tinv = p->d_tinv;
+        hipLaunchKernelGGL(ls_prepare_kernel, dim3(nblocks), dim3(LS_THREADS),
+                           sizeof(double2) * ((size_t)3 * T + 1), stream, pa);
+        PRC_LAUNCH_CHECK();
+        rc = launch_solve(0, cur, cur_stride);
+        if (rc) return rc;
+    }
+    for (int ib = 0; ib < nbins; ++ib) {
+        const PhaseRamp pr = make_ramp(bins[ib], sample_rate, 0.0);
+        const bool has_next = ib + 1 < nbins;
+        float2* dst = has_next ? p->d_tmp[ib & 1] : (float2*)out;
+        const int64_t dst_stride = has_next ? n : out_stride;
+        LsFftArgs xa;
+        fill_xa(xa, p, ref, stride, cur, cur_stride, dst, dst_stride, pr);
+        double theta_next = 0.0;
+        if (has_next) {
+            const PhaseRamp prn = make_ramp(bins[ib + 1], sample_rate, 0.0);
+            theta_next = theta_exact(ib + 1);
+            PRC_REQUIRE(!prn.enabled || fabs(theta_next) * (p->desc.peek + 1) <= 0.3, PRC_EUNSUPPORTED,
+                        "prc_ls_execute: |2 pi fc/Fs| * peek too large for the FFT kernels (use method=1)");
+            xa.has_next = 1;
+            xa.rot2 = prn.enabled;
+            xa.pr2 = prn;
+        }
+        const double theta_eff = pr.enabled ? (double)pr.a32 * (double)pr.rcp32 : 0.0;
+        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
+        rc = ls_launch_fused_cached(xa, theta_exact(ib), theta_next, -theta_eff * (double)n, p->fft_waves,
+                                    nblocks, stream);
+        if (rc) return rc;
+        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 3], stream));
+        cur = dst;
+        cur_stride = dst_stride;
+        if (has_next) {
+            if (p->profiling) {
+                PRC_HIP(hipEventRecord(p->ev[4 * (ib + 1) + 0], stream));
+                PRC_HIP(hipEventRecord(p->ev[4 * (ib + 1) + 1], stream));
+            }
+            rc = launch_solve(ib + 1, cur, cur_stride);
+            if (rc) return rc;
+        }
+    }
+    return PRC_OK;
+}
+
 extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, int64_t stride,
                               void* out, int64_t out_stride, int32_t nblocks, double sample_rate,
                               const double* bins, int32_t nbins, double reg, void* taps_out,
@@ -734,8 +874,6 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
     std::lock_guard<std::mutex> lk(p->mtx);
     const int T = p->T;
     const int64_t n = p->desc.n;
-    const float2* cur = (const float2*)srv;
-    int64_t cur_stride = stride;
     if (p->profiling) {
         while ((int)p->ev.size() < 4 * nbins) {
             hipEvent_t e;
@@ -744,112 +882,79 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
         }
         p->ev_bins = nbins;
     }
-    for (int ib = 0; ib < nbins; ++ib) {
-        const PhaseRamp pr = make_ramp(bins[ib], sample_rate, 0.0);
-        float2* dst;
-        int64_t dst_stride;
-        if (ib == nbins - 1) {
-            dst = (float2*)out;
-            dst_stride = out_stride;
-        } else {
-            dst = p->d_tmp[ib & 1];
-            dst_stride = n;
-        }
-        CorrArgs ca;
-        ca.p_src = (const float2*)ref;  ca.p_stride = stride;
-        ca.s1_src = (const float2*)ref; ca.s1_stride = stride;
-        ca.s2_src = cur;                ca.s2_stride = cur_stride;
-        ca.n = n;
-        ca.nlags = T;
-        ca.peek_p = p->desc.peek;  ca.peek_s1 = p->desc.peek;  ca.peek_s2 = 0;
-        ca.rot_p = pr.enabled;     ca.rot_s1 = pr.enabled;     ca.rot_s2 = 0;
-        ca.circular = p->desc.circular;
-        ca.pr = pr;
-        ca.partial = p->d_partial;
-        ca.nblk = p->nblk;
-        const double theta = 2.0 * 3.14159265358979323846 * bins[ib] / sample_rate;
-        if (p->method == 2 && pr.enabled) {
-            PRC_REQUIRE(!p->desc.circular, PRC_EUNSUPPORTED,
-                        "prc_ls_execute: Doppler-shifted bins with the circular (LS_Filter) form need method=1");
-            PRC_REQUIRE(fabs(theta) * (p->desc.peek + 1) <= 0.3, PRC_EUNSUPPORTED,
-                        "prc_ls_execute: |2 pi fc/Fs| * peek = %g too large for the FFT kernels (use method=1)",
-                        fabs(theta) * p->desc.peek);
-        }
-        LsFftArgs xa;
-        xa.ref = (const float2*)ref;  xa.ref_stride = stride;
-        xa.srv = cur;                 xa.srv_stride = cur_stride;
-        xa.out = dst;                 xa.out_stride = dst_stride;
-        xa.partial = p->d_partial;
-        xa.taps = p->d_taps;
-        xa.tab = nullptr;
-        xa.n = n;
-        xa.T = T;
-        xa.peek = p->desc.peek;
-        xa.circular = p->desc.circular;
-        xa.rot = pr.enabled;
-        xa.pr = pr;
-        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 0], stream));
-        // shared-inverse path: the wrap perturbation (gamma-1) S_e must be small against c_0 for the
-        // refinement to converge fast (ratio ~ peek/N); short blocks keep the per-bin Levinson solve
-        const bool shared = p->d_tinv && nbins > 1 && n >= 2000LL * (p->desc.peek > 0 ? p->desc.peek : 1);
-        int rc = p->method == 2 ? ls_launch_corr_fft(xa, theta, p->fft_waves, nblocks, !(shared && ib > 0), stream)
-                                : launch_corr(ca, true, nblocks, stream);
+    // The cached chain needs the wrap perturbation (gamma-1) S_e to be small against c_0 for the
+    // refinement to converge fast (ratio ~ peek/N); short blocks and single-bin calls keep the
+    // per-bin Levinson solve.
+    p->last_cached = p->d_tinv && nbins > 1 && n >= 2000LL * (p->desc.peek > 0 ? p->desc.peek : 1);
+    if (p->last_cached) {
+        int rc = run_cached_chain(p, ref, srv, stride, out, out_stride, nblocks, sample_rate, bins, nbins, reg,
+                                  stream);
         if (rc) return rc;
-        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 1], stream));
-        if (shared) {
-            // effective slope of the reference's float32 ramp: fl32(2 pi f) * fl32(1/Fs)
-            const double theta_eff = (double)pr.a32 * (double)pr.rcp32;
-            if (ib == 0) {
-                LsPrepArgs pa;
-                pa.partial = p->d_partial;  pa.ref = (const float2*)ref;  pa.ref_stride = stride;
-                pa.n = n;  pa.nblk = p->nblk;  pa.T = T;  pa.peek = p->desc.peek;  pa.reg = reg;
-                pa.theta0 = pr.enabled ? theta_eff : 0.0;
-                pa.c0 = p->d_c0;  pa.se = p->d_se;  pa.tinv = p->d_tinv;
-                hipLaunchKernelGGL(ls_prepare_kernel, dim3(nblocks), dim3(LS_THREADS),
-                                   sizeof(double2) * ((size_t)3 * T + 1), stream, pa);
-                PRC_LAUNCH_CHECK();
+    } else {
+        const float2* cur = (const float2*)srv;
+        int64_t cur_stride = stride;
+        for (int ib = 0; ib < nbins; ++ib) {
+            const PhaseRamp pr = make_ramp(bins[ib], sample_rate, 0.0);
+            float2* dst = ib == nbins - 1 ? (float2*)out : p->d_tmp[ib & 1];
+            const int64_t dst_stride = ib == nbins - 1 ? out_stride : n;
+            const double theta = 2.0 * 3.14159265358979323846 * bins[ib] / sample_rate;
+            if (p->method == 2 && pr.enabled) {
+                PRC_REQUIRE(!p->desc.circular, PRC_EUNSUPPORTED,
+                            "prc_ls_execute: Doppler-shifted bins with the circular (LS_Filter) form need method=1");
+                PRC_REQUIRE(fabs(theta) * (p->desc.peek + 1) <= 0.3, PRC_EUNSUPPORTED,
+                            "prc_ls_execute: |2 pi fc/Fs| * peek = %g too large for the FFT kernels (use method=1)",
+                            fabs(theta) * p->desc.peek);
             }
-            LsSolveArgs sa;
-            sa.partial = p->d_partial;  sa.c0 = p->d_c0;  sa.se = p->d_se;  sa.tinv = p->d_tinv;
-            sa.taps = p->d_taps;  sa.n = n;  sa.nblk = p->nblk;  sa.T = T;
-            sa.theta = pr.enabled ? theta_eff : 0.0;
-            // one refinement squares the wrap perturbation (~ a few peek/N); two for short blocks
-            sa.nref = !pr.enabled ? 0 : (n >= 100000LL * (p->desc.peek > 0 ? p->desc.peek : 1) ? 1 : 2);
-            {
-                const int RP = (T + 63) & ~63;
-                const int parts = LSS_THREADS / RP > 0 ? LSS_THREADS / RP : 1;
-                hipLaunchKernelGGL(ls_solve_kernel, dim3(nblocks), dim3(LSS_THREADS),
-                                   sizeof(double2) * ((size_t)5 * T + (size_t)parts * RP), stream, sa);
+            LsFftArgs xa;
+            fill_xa(xa, p, ref, stride, cur, cur_stride, dst, dst_stride, pr);
+            if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 0], stream));
+            int rc;
+            if (p->method == 2) {
+                rc = ls_launch_corr_fft(xa, theta, p->fft_waves, nblocks, true, stream);
+            } else {
+                CorrArgs ca;
+                ca.p_src = (const float2*)ref;  ca.p_stride = stride;
+                ca.s1_src = (const float2*)ref; ca.s1_stride = stride;
+                ca.s2_src = cur;                ca.s2_stride = cur_stride;
+                ca.n = n;
+                ca.nlags = T;
+                ca.peek_p = p->desc.peek;  ca.peek_s1 = p->desc.peek;  ca.peek_s2 = 0;
+                ca.rot_p = pr.enabled;     ca.rot_s1 = pr.enabled;     ca.rot_s2 = 0;
+                ca.circular = p->desc.circular;
+                ca.pr = pr;
+                ca.partial = p->d_partial;
+                ca.nblk = p->nblk;
+                rc = launch_corr(ca, true, nblocks, stream);
             }
-            PRC_LAUNCH_CHECK();
-        } else {
+            if (rc) return rc;
+            if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 1], stream));
             hipLaunchKernelGGL(levinson_wave_kernel, dim3(nblocks), dim3(64), levinson_lds(T), stream,
                                p->d_partial, p->nblk, T, reg, p->d_taps);
             PRC_LAUNCH_CHECK();
+            if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
+            if (p->method == 2) {
+                rc = ls_launch_fir_fft(xa, theta, nblocks, stream);
+                if (rc) return rc;
+            } else {
+                FirArgs fa;
+                fa.ref = (const float2*)ref;  fa.ref_stride = stride;
+                fa.srv = cur;                 fa.srv_stride = cur_stride;
+                fa.out = dst;                 fa.out_stride = dst_stride;
+                fa.taps = p->d_taps;
+                fa.n = n;
+                fa.T = T;
+                fa.peek = p->desc.peek;
+                fa.circular = p->desc.circular;
+                fa.rot = pr.enabled;
+                fa.pr = pr;
+                dim3 grid((unsigned)ceil_div64(n, FIR_SPAN), (unsigned)nblocks);
+                hipLaunchKernelGGL(fir_subtract_kernel, grid, dim3(LS_THREADS), fir_lds(T), stream, fa);
+                PRC_LAUNCH_CHECK();
+            }
+            if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 3], stream));
+            cur = dst;
+            cur_stride = dst_stride;
         }
-        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
-        FirArgs fa;
-        fa.ref = (const float2*)ref;  fa.ref_stride = stride;
-        fa.srv = cur;                 fa.srv_stride = cur_stride;
-        fa.out = dst;                 fa.out_stride = dst_stride;
-        fa.taps = p->d_taps;
-        fa.n = n;
-        fa.T = T;
-        fa.peek = p->desc.peek;
-        fa.circular = p->desc.circular;
-        fa.rot = pr.enabled;
-        fa.pr = pr;
-        if (p->method == 2) {
-            rc = ls_launch_fir_fft(xa, theta, nblocks, stream);
-            if (rc) return rc;
-        } else {
-            dim3 grid((unsigned)ceil_div64(n, FIR_SPAN), (unsigned)nblocks);
-            hipLaunchKernelGGL(fir_subtract_kernel, grid, dim3(LS_THREADS), fir_lds(T), stream, fa);
-            PRC_LAUNCH_CHECK();
-        }
-        if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 3], stream));
-        cur = dst;
-        cur_stride = dst_stride;
     }
     if (taps_out)
         PRC_HIP(hipMemcpyAsync(taps_out, p->d_taps, sizeof(double2) * (size_t)nblocks * T,
@@ -865,9 +970,11 @@ extern "C" int prc_ls_set_profiling(prc_ls_plan* p, int32_t enable) {
     return PRC_OK;
 }
 
-// ms[0..2] = total milliseconds of the correlation / Levinson / FIR kernels of the LAST execute
-// (summed over its Doppler bins); synchronises on the recorded events.
-extern "C" int prc_ls_get_profile(prc_ls_plan* p, double* ms, int32_t* launches_per_kind) {
+// ms[0..2] = total milliseconds of the correlation / solve / FIR kernels of the LAST execute (summed
+// over its Doppler bins), launches[0..2] = kernel launches behind each figure.  In the cached chain
+// the correlation of bin i+1 runs inside the FIR kernel of bin i, so only bin 0 has a correlation
+// launch of its own.  Synchronises on the recorded events.
+extern "C" int prc_ls_get_profile(prc_ls_plan* p, double* ms, int32_t* launches) {
     PRC_REQUIRE(p && ms, PRC_EINVAL, "prc_ls_get_profile: null argument");
     std::lock_guard<std::mutex> lk(p->mtx);
     PRC_REQUIRE(p->profiling && p->ev_bins > 0, PRC_EINVAL, "prc_ls_get_profile: nothing recorded");
@@ -880,7 +987,11 @@ extern "C" int prc_ls_get_profile(prc_ls_plan* p, double* ms, int32_t* launches_
             ms[k] += t;
         }
     }
-    if (launches_per_kind) *launches_per_kind = p->ev_bins;
+    if (launches) {
+        launches[0] = p->last_cached ? 1 : p->ev_bins;
+        launches[1] = p->ev_bins;
+        launches[2] = p->ev_bins;
+    }
     return PRC_OK;
 }
 

@@ -437,6 +437,292 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fir_fft_lin_kernel(LsFft
     }
 }
 
+// ---- cached-spectrum chain (linear boundary, LS_Filter_Multiple) ---------------------------------
+// Everything is expressed with the UNROTATED rho = roll(ref, -peek); the Doppler rotation of bin f
+// moves onto the surveillance stream (s~[n] = s[n] e^{-j theta (n+peek)}) and onto the FIR output
+// (identities checked in tools/ls_shared_inverse_model.py).  Then X_p = FFT(rho[block p]) is the
+// SAME for every bin: the first bin writes it to HBM (8 KB per 1025-T samples), later bins read it:
+//   first bin        : 3 FFTs per piece  (X_p, rho piece, s~ piece) -> c_0 and b_0 partials, cache
+//   FIR(i)+corr(i+1) : 2 FFTs per block  (inverse of X_p H~_i; forward of the cleaned piece)
+// Correlations use the "roles swapped" block form: with the piece placed in slots [ext, ext+cnt) and
+// zeros elsewhere,  sum_n s[n] conj(rho[n-k]) = IFFT( FFT(s slots) conj(X_p) )[k]  for k <= ext.
+// The <= peek samples whose source wrapped (phase ramp restarted, factor gamma) are corrected
+// exactly in the solve kernel (right-hand side) and in ls_edge_fix_kernel (last peek outputs).
+__device__ __forceinline__ void cmac_bconj(float2& w, float2 u, float2 x) {   // w += u * conj(x)
+    w.x = fmaf(u.x, x.x, w.x);
+    w.x = fmaf(u.y, x.y, w.x);
+    w.y = fmaf(u.y, x.x, w.y);
+    w.y = fmaf(-u.x, x.y, w.y);
+}
+
+__global__ __launch_bounds__(64 * LSF_WAVES, 1) void ls_corr_cached_kernel(LsFftArgs a) {
+    constexpr bool FIRST = true;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* tab = reinterpret_cast<float2*>(smem_raw);
+    float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
+    fft_load_tables(tab, a.tab);
+    __syncthreads();
+    const FftLane f = fft_lane_setup();
+    const int lane = f.lane;
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wg = blockIdx.x * LSF_WAVES + wave_id;
+    const int nwaves = gridDim.x * LSF_WAVES;
+    const int b = blockIdx.y;
+    const float2* __restrict__ ref = a.ref + (int64_t)b * a.ref_stride;
+    const float2* __restrict__ srv = a.srv + (int64_t)b * a.srv_stride;
+    const int n = (int)a.n;
+    const int T = a.T, B = a.piece, ext = T - 1, peek = a.peek;
+    const int npieces = (n + B - 1) / B;
+    float2* __restrict__ cache = a.cache + (int64_t)b * npieces * FFTW_P;
+    const unsigned vo8 = (unsigned)lane * 8u;
+    const unsigned vslot = vo8 - (unsigned)ext * 8u;          // slot idx -> piece sample idx-ext (idx<ext: out of range)
+    const __amdgpu_buffer_rsrc_t rx = prc_rsrc(ref + peek, lsf_clampu(n - peek) * 8u);
+
+    float2 wrr[16], wrs[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { wrr[m] = make_float2(0.f, 0.f); wrs[m] = make_float2(0.f, 0.f); }
+
+    float2 xn[16];                                            // block of the next piece (prefetched)
+    auto issue_x = [&](int p) {
+        const bool live = p < npieces;
+        if (FIRST) {
+            const int mstart = (live ? p * B : n) - ext;
+            const unsigned voff = vo8 + (unsigned)mstart * 8u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rx, voff + 512u * r, 0u);
+        } else {
+            const __amdgpu_buffer_rsrc_t rc = prc_rsrc(cache + (int64_t)(live ? p : 0) * FFTW_P,
+                                                       live ? FFTW_P * 8u : 0u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rc, vo8, 512u * r);
+        }
+    };
+    issue_x(wg);
+    for (int p = wg; p < npieces; p += nwaves) {
+        const int n0 = p * B;
+        const int cnt = (n - n0) < B ? (n - n0) : B;
+        const int mstart = n0 - ext;
+        float2 x[16], u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = xn[r];
+        // surveillance piece in slots [ext, ext+cnt), rotated by e^{-j theta (n+peek)}
+        {
+            const __amdgpu_buffer_rsrc_t rs = prc_rsrc(srv + n0, lsf_clampu(cnt) * 8u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = prc_buf_load_c64(rs, vslot + 512u * r, 0u);
+        }
+        float2 sbase = make_float2(1.f, 0.f);
+        if (a.rot) {
+            sbase = phase_rot(a.pr, (int64_t)mstart + lane + peek);
+            sbase.y = -sbase.y;
+        }
+        if (FIRST) {
+            // wrapped tail of rho (source index restarts at ref[0]); unrotated, so no phase here
+            const int wstart = n - peek - mstart;
+            if (peek > 0 && wstart < FFTW_P) {
+                int cw = FFTW_P - wstart;
+                if (cw > peek) cw = peek;
+                const __amdgpu_buffer_rsrc_t rw = prc_rsrc(ref, lsf_clampu(cw) * 8u);
+                const unsigned voff = vo8 - (unsigned)wstart * 8u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float2 w = prc_buf_load_c64(rw, voff + 512u * r, 0u);
+                    x[r].x += w.x;
+                    x[r].y += w.y;
+                }
+            }
+            // rho piece in slots [ext, ext+cnt): the same samples, masked by the range check
+            float2 up[16];
+            {
+                int cu = cnt;
+                if (n - peek - n0 < cu) cu = n - peek - n0;
+                const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + peek + n0, lsf_clampu(cu) * 8u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) up[r] = prc_buf_load_c64(ru, vslot + 512u * r, 0u);
+                const int wst = n - peek - n0;                // first wrapped sample of the piece
+                if (peek > 0 && wst < cnt) {
+                    const __amdgpu_buffer_rsrc_t rw = prc_rsrc(ref, lsf_clampu(cnt - wst) * 8u);
+                    const unsigned voff = vslot - (unsigned)wst * 8u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float2 w = prc_buf_load_c64(rw, voff + 512u * r, 0u);
+                        up[r].x += w.x;
+                        up[r].y += w.y;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fft1024_fwd(x, tile, tab, f);
+            float2* __restrict__ cp = cache + (int64_t)p * FFTW_P;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cp[64 * r + lane] = x[r];
+            fft1024_fwd(up, tile, tab, f);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) cmac_bconj(wrr[m], up[m], x[m]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (a.rot) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float2 st = a.step[r];
+                st.y = -st.y;
+                u[r] = cmul(u[r], cmul(sbase, st));
+            }
+        }
+        issue_x(p + nwaves);
+        __builtin_amdgcn_sched_barrier(0);
+        fft1024_fwd(u, tile, tab, f);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) cmac_bconj(wrs[m], u[m], x[m]);
+    }
+    if (FIRST) fft1024_inv(wrr, tile, tab, f);
+    fft1024_inv(wrs, tile, tab, f);
+    // partial[b][wave][0/1][lag] holds conj(g): the prepare / solve prologues conjugate back
+    float2* __restrict__ part = a.partial + ((int64_t)b * nwaves + wg) * 2 * T;
+    const float sc = 1.0f / 1024.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lag = 64 * r + lane;
+        if (lag < T) {
+            if (FIRST) part[lag] = make_float2(wrr[r].x * sc, -wrr[r].y * sc);
+            part[T + lag] = make_float2(wrs[r].x * sc, -wrs[r].y * sc);
+        }
+    }
+}
+
+// FIR of bin i fused with the cross-correlation of bin i+1 (cached-spectrum chain): per block the
+// wave reads X_p (cache) and the surveillance piece once, writes the cleaned piece once and keeps it
+// in registers as the input of the next bin's correlation -- 20 KB of HBM traffic per 1025-T
+// samples per bin instead of 34 KB for the two separate kernels.
+__global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* tab = reinterpret_cast<float2*>(smem_raw);
+    float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
+    fft_load_tables(tab, a.tab);
+    __syncthreads();
+    const FftLane f = fft_lane_setup();
+    const int lane = f.lane;
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wg = blockIdx.x * LSF_WAVES + wave_id;
+    const int nwaves = gridDim.x * LSF_WAVES;
+    const int b = blockIdx.y;
+    const float2* __restrict__ ref = a.ref + (int64_t)b * a.ref_stride;
+    const float2* __restrict__ srv = a.srv + (int64_t)b * a.srv_stride;
+    float2* __restrict__ out = a.out + (int64_t)b * a.out_stride;
+    const double2* __restrict__ taps = a.taps_t + (int64_t)b * a.T;
+    const int n = (int)a.n;
+    const int T = a.T, B = a.piece, ext = T - 1, peek = a.peek;
+    const int nblocks = (n + B - 1) / B;
+    const float2* __restrict__ cache = a.cache + (int64_t)b * nblocks * FFTW_P;
+    const unsigned vo8 = (unsigned)lane * 8u;
+    const unsigned vslot = vo8 - (unsigned)ext * 8u;
+
+    float2 h[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int idx = 64 * r + lane;
+        const double2 t = taps[idx < T ? idx : 0];
+        h[r] = idx < T ? make_float2((float)t.x, (float)t.y) : make_float2(0.f, 0.f);
+    }
+    fft1024_fwd(h, tile, tab, f);
+    const float sc = 1.0f / 1024.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { h[r].x *= sc; h[r].y *= sc; }
+
+    float2 wrs[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wrs[m] = make_float2(0.f, 0.f);
+
+    float2 xn[16];
+    auto issue_x = [&](int p) {
+        const bool live = p < nblocks;
+        const __amdgpu_buffer_rsrc_t rc = prc_rsrc(cache + (int64_t)(live ? p : 0) * FFTW_P,
+                                                   live ? FFTW_P * 8u : 0u);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rc, vo8, 512u * r);
+    };
+    issue_x(wg);
+    for (int p = wg; p < nblocks; p += nwaves) {
+        const int n0 = p * B;
+        const int cnt = (n - n0) < B ? (n - n0) : B;
+        float2 xc[16], y[16], sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { xc[r] = xn[r]; y[r] = cmul(xn[r], h[r]); }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(p + nwaves);
+        {
+            const __amdgpu_buffer_rsrc_t rs = prc_rsrc(srv + n0, lsf_clampu(cnt) * 8u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = prc_buf_load_c64(rs, vslot + 512u * r, 0u);
+        }
+        float2 obase = make_float2(1.f, 0.f), sbase = make_float2(1.f, 0.f);
+        if (a.rot) obase = phase_rot(a.pr, (int64_t)n0 - ext + lane + peek);
+        if (a.rot2) {
+            sbase = phase_rot(a.pr2, (int64_t)n0 - ext + lane + peek);
+            sbase.y = -sbase.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fft1024_inv(y, tile, tab, f);
+        // last `peek` outputs of the block: rho samples whose ramp restarted carry gamma instead of 1
+        if (a.rot && peek > 0 && n0 + cnt > n - peek) {
+            const float2 g1 = a.gamma_m1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = n0 + 64 * r + lane - ext;
+                const int over = nn - (n - peek);            // 0..peek-1 for affected outputs
+                if (over >= 0 && nn < n) {
+                    float2 acc = make_float2(0.f, 0.f);
+                    for (int k = 0; k <= over && k < T; ++k) {
+                        const double2 wk = taps[k];
+                        cmac(acc, make_float2((float)wk.x, (float)wk.y), ref[over - k]);   // rho[nn-k] = ref[nn-k+peek-n]
+                    }
+                    const float2 c = cmul(g1, acc);
+                    y[r].x += c.x;
+                    y[r].y += c.y;
+                }
+            }
+        }
+        const __amdgpu_buffer_rsrc_t ro = prc_rsrc(out + n0, lsf_clampu(cnt) * 8u);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float2 yy = y[r];
+            if (a.rot) yy = cmul(yy, cmul(obase, a.step[r]));
+            const float2 o = make_float2(sv[r].x - yy.x, sv[r].y - yy.y);
+            prc_v2u d;
+            d.x = __float_as_uint(o.x);
+            d.y = __float_as_uint(o.y);
+            __builtin_amdgcn_raw_buffer_store_b64(d, ro, (int)(vslot + 512u * r), 0, 0);
+            // the cleaned piece stays in registers as the next bin's surveillance piece:
+            // slots [ext, ext+cnt) only (the other slots of y are circular-convolution garbage)
+            const int idx = 64 * r + lane;
+            const bool in = idx >= ext && idx < ext + cnt;
+            float2 st = a.step2[r];
+            st.y = -st.y;
+            const float2 sr = a.rot2 ? cmul(o, cmul(sbase, st)) : o;
+            y[r] = in ? sr : make_float2(0.f, 0.f);
+        }
+        if (a.has_next) {
+            fft1024_fwd(y, tile, tab, f);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) cmac_bconj(wrs[m], y[m], xc[m]);
+        }
+    }
+    if (a.has_next) {
+        fft1024_inv(wrs, tile, tab, f);
+        float2* __restrict__ part = a.partial + ((int64_t)b * nwaves + wg) * 2 * T;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lag = 64 * r + lane;
+            if (lag < T) part[T + lag] = make_float2(wrs[r].x * sc, -wrs[r].y * sc);
+        }
+    }
+}
+
+int64_t ls_cache_elems_per_block(int64_t n, int T) {
+    const int64_t B = FFTW_P - (T - 1);
+    return ((n + B - 1) / B) * FFTW_P;
+}
+
 bool ls_fft_supported(int T) { return T >= 2 && T - 1 <= 768; }
 
 int ls_fft_waves_per_block(int64_t n, int T) {
@@ -493,6 +779,34 @@ int ls_launch_fir_fft(LsFftArgs a, double theta, int nblocks, hipStream_t stream
         hipLaunchKernelGGL(ls_fir_fft_lin_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
     else
         hipLaunchKernelGGL(ls_fir_fft_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}
+
+int ls_launch_corr_cached(LsFftArgs a, double theta, int waves_per_block, int nblocks, hipStream_t stream) {
+    fill_common(a, a.T, theta);
+    int rc = fftw_device_tables(&a.tab);
+    if (rc) return rc;
+    dim3 grid((unsigned)(waves_per_block / LSF_WAVES), (unsigned)nblocks);
+    const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE);
+    hipLaunchKernelGGL(ls_corr_cached_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}
+
+int ls_launch_fused_cached(LsFftArgs a, double theta, double theta_next, double gamma_angle, int waves_per_block,
+                           int nblocks, hipStream_t stream) {
+    fill_common(a, a.T, theta);
+    for (int r = 0; r < 16; ++r) {
+        const double ang = theta_next * 64.0 * r;
+        a.step2[r] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    a.gamma_m1 = make_float2((float)(cos(gamma_angle) - 1.0), (float)sin(gamma_angle));
+    int rc = fftw_device_tables(&a.tab);
+    if (rc) return rc;
+    dim3 grid((unsigned)(waves_per_block / LSF_WAVES), (unsigned)nblocks);
+    const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE);
+    hipLaunchKernelGGL(ls_fused_cached_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }

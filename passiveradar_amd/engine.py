@@ -113,11 +113,12 @@ class LsPlan:
         check(lib().prc_ls_set_profiling(self._h, int(bool(enable))))
 
     def get_profile(self):
-        """(ms_corr, ms_levinson, ms_fir, launches_per_kind) of the last execute"""
+        """((ms_corr, ms_solve, ms_fir), (launches_corr, launches_solve, launches_fir)) of the last
+        execute; in the cached chain the correlation of bin i+1 runs inside the FIR kernel of bin i"""
         ms = (C.c_double * 3)()
-        k = C.c_int32()
-        check(lib().prc_ls_get_profile(self._h, ms, C.byref(k)))
-        return ms[0], ms[1], ms[2], k.value
+        k = (C.c_int32 * 3)()
+        check(lib().prc_ls_get_profile(self._h, ms, k))
+        return (ms[0], ms[1], ms[2]), (k[0], k[1], k[2])
 
     def close(self):
         if getattr(self, "_h", None):

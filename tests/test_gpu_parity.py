@@ -194,3 +194,55 @@ def test_nlms_long_filter_vs_c_oracle():
     exp, etaps = c_oracle.nlms(ref, srv, L, 0.02, 10)
     out, taps = NLMS_filter(ref, srv, L, 0.02, 10, None, True)
     assert rel_err(out, exp) < TOL and rel_err(taps, etaps) < TOL
+
+
+@pytest.mark.parametrize("n,R,F", [(600, 0, 4), (1000, 5, 1), (2047, 9, 7), (2048, 1, 2), (5003, 1000, 3)])
+def test_caf_edge_shapes(n, R, F):
+    """degenerate spans: one lag column, one Doppler bin, CPI shorter than one FFT piece,
+    range span close to the CPI length (several lag blocks, wrap inside every piece)"""
+    from passiveradar_amd.range_doppler_processing import fast_xambg
+    ref, srv = scene.make_scene(n, 1e4, max(R, 1), 5150 + n)
+    exp = O.fast_xambg(ref, srv, R, F, n, None)
+    out = fast_xambg(ref, srv, R, F, n, None)
+    assert out.shape == (F, R + 1, 1)
+    assert rel_err(out, exp) < TIGHT
+
+
+def test_ls_and_nlms_edge_shapes():
+    from passiveradar_amd.clutter_removal import LS_Filter_Multiple, LS_Filter_Toeplitz, NLMS_filter
+    ref, srv = scene.make_scene(700, 1e4, 8, 616)
+    out, taps = LS_Filter_Toeplitz(ref, srv, 3, 0, True)               # no non-causal taps, tiny filter
+    exp, etaps = O.LS_Filter_Toeplitz(ref, srv, 3, 0, True)
+    assert rel_err(out, exp) < TIGHT and rel_err(taps, etaps) < TIGHT
+    assert rel_err(LS_Filter_Multiple(ref, srv, 5, 1e4, [3, 0]), O.LS_Filter_Multiple(ref, srv, 5, 1e4, [3, 0])) < TOL
+    assert LS_Filter_Multiple(ref, srv, 5, 1e4, []) is srv               # empty bin list: input returned (:178)
+    y = NLMS_filter(ref[:30], srv[:30], 25, 0.1)                         # n <= T: no step runs, all zeros
+    assert y.shape == (30,) and not y.any()
+    with pytest.raises(ValueError):
+        LS_Filter_Toeplitz(ref[:20], srv[:20], 30)                       # more taps than samples
+
+
+def test_concurrent_callers():
+    """dask-style: worker threads call the drop-in functions concurrently (one plan cache per thread)"""
+    import threading
+    from passiveradar_amd.clutter_removal import LS_Filter_Toeplitz
+    from passiveradar_amd.range_doppler_processing import fast_xambg
+    n, R, F = 8192, 30, 64
+    cases = [scene.make_scene(n, 1e4, R, 900 + i) for i in range(6)]
+    exp = [(O.fast_xambg(a, s, R, F), O.LS_Filter_Toeplitz(a, s, R)) for a, s in cases]
+    got = [None] * len(cases)
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = (fast_xambg(cases[i][0], cases[i][1], R, F), LS_Filter_Toeplitz(cases[i][0], cases[i][1], R))
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for (gx, gl), (ex, el) in zip(got, exp):
+        assert rel_err(gx, ex) < TIGHT and rel_err(gl, el) < TIGHT

@@ -76,3 +76,44 @@ if __name__ == "__main__":
         e1 = np.abs(x - w_ref).max() / np.abs(w_ref).max()
         print(f"f={f:+.2f}  c_f model err {np.abs(cf - cf_model).max() / abs(cf[0]):.2e}   "
               f"taps err: no refinement {e0:.2e}, one refinement {e1:.2e}")
+
+
+def check_unrotated_reference_form():
+    """Second identity set (cached-spectrum LS chain): everything is expressed with the UNROTATED
+    rho = roll(ref, -peek), the rotation moves to the surveillance stream and to the output:
+        s~[n]   = s[n] e^{-j theta (n+peek)}
+        b_f[k]  = e^{j theta k} ( sum_{n>=k} s~[n] conj(rho[n-k]) + (conj(gamma)-1) E_b[k] ),
+        E_b[k]  = sum_{m=N-peek}^{N-1-k} conj(rho[m]) s~[m+k]                     (k < peek, else 0)
+        w~[k]   = w[k] e^{-j theta k}
+        out[n]  = s[n] - e^{j theta (n+peek)} ( (rho * w~)[n] + [n >= N-peek] (gamma-1) sum_{k<=n-(N-peek)} w~[k] rho[n-k] )
+    """
+    rng = np.random.default_rng(5)
+    N, L, peek, fs = 5000, 24, 10, 9000.0
+    T = L + peek
+    ref = ((rng.standard_normal(N) + 1j * rng.standard_normal(N)) / np.sqrt(2)).astype(np.complex64)
+    srv = (np.roll(ref, 3) + 0.2 * np.roll(ref, 7) + 0.05 * rng.standard_normal(N)).astype(np.complex64)
+    rho = np.roll(ref, -peek).astype(complex)
+    for f in (1.0, -0.37):
+        theta = 2 * np.pi * f / fs
+        nn = np.arange(N)
+        rf = np.roll(ref.astype(complex) * np.exp(1j * theta * nn), -peek)       # reference form (exact phase)
+        gamma = np.exp(-1j * theta * N)
+        st = srv.astype(complex) * np.exp(-1j * theta * (nn + peek))
+        b_ref = np.array([np.vdot(rf[:N - k], srv.astype(complex)[k:]) for k in range(T)])
+        Bt = np.array([np.vdot(rho[:N - k], st[k:]) for k in range(T)])
+        Eb = np.array([sum(np.conj(rho[m]) * st[m + k] for m in range(N - peek, N - k)) if k < peek else 0.0
+                       for k in range(T)])
+        b_model = np.exp(1j * theta * np.arange(T)) * (Bt + (np.conj(gamma) - 1) * Eb)
+        w = rng.standard_normal(T) + 1j * rng.standard_normal(T)
+        out_ref = srv.astype(complex) - np.convolve(rf, w)[:N]
+        wt = w * np.exp(-1j * theta * np.arange(T))
+        y = np.convolve(rho, wt)[:N]
+        for n in range(N - peek, N):
+            y[n] += (gamma - 1) * sum(wt[k] * rho[n - k] for k in range(0, n - (N - peek) + 1))
+        out_model = srv.astype(complex) - np.exp(1j * theta * (nn + peek)) * y
+        print(f"f={f:+.2f}  b_f model err {np.abs(b_ref - b_model).max() / np.abs(b_ref).max():.2e}   "
+              f"FIR model err {np.abs(out_ref - out_model).max():.2e}")
+
+
+if __name__ == "__main__":
+    check_unrotated_reference_form()
