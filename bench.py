@@ -102,11 +102,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=64, help="frames (= hop chunks) per GPU per step")
+    ap.add_argument("--frames", type=int, default=256, help="frames (= hop chunks) per GPU per step")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--caf-method", type=int, default=0, help="0 auto, 1 direct, 2 fft")
     ap.add_argument("--doppler", type=int, default=0, help="0 auto, 1 rocfft, 2 fused")
-    ap.add_argument("--ls-streams", type=int, default=2, help="HIP streams the LS half-batches run on")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run LS and CAF back to back on one stream instead of pipelining sub-batches on two")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-clutter", action="store_true", help="CAF only (reported as a different metric)")
     args = ap.parse_args()
@@ -133,7 +134,7 @@ def main():
     B = args.frames
     C = n // 2
     be = prstream.HipBackend(n, R, F, fs, clutter=clutter, batch=B, device=device,
-                             caf_method=args.caf_method, doppler_method=args.doppler, ls_streams=args.ls_streams)
+                             caf_method=args.caf_method, doppler_method=args.doppler, overlap=not args.no_overlap)
     ref, srv = synth_stream(torch, B, C, fs, R, 20260926 + rank, device)
     ref_pad = be.padded(ref)
     srv_pad = be.padded(srv)
@@ -141,8 +142,7 @@ def main():
     shard = prstream.Shard(rank, world, B * world, rank * B, (rank + 1) * B, 0, B)
 
     def step():
-        clean = be.clean(ref_pad, srv_pad, B)
-        frames = be.frames(ref_pad, clean, 0, B)
+        frames = be.run(ref_pad, srv_pad, B, 0, B)
         if world > 1:
             return prstream.gather_frames(frames, shard)
         return frames
@@ -193,14 +193,15 @@ def main():
                              "launches_per_step": 1, "bytes": B * 16.0 * F * (R + 1)}
         if clutter == "ls":
             be.ls.set_profiling(True)
+            nb_ls = min(B, be.sub)
             acc = np.zeros(3)
             for _ in range(reps):
-                be.clean(ref_pad, srv_pad, B)
+                be._clean_range(ref_pad, srv_pad, clean, 0, nb_ls, s)
                 ms3, k3 = be.ls.get_profile()
                 acc += ms3
             be.ls.set_profiling(False)
             acc /= reps
-            nb = B if len(be.ls_lanes) < 2 else be.ls_per     # blocks behind one launch
+            nb = min(B, be.sub)                                # blocks behind one LS launch
             T = R + 10
             fused = k3[0] == 1 and k3[2] > 1                   # cached-spectrum chain: corr(i+1) inside FIR(i)
             kt["ls_correlate"] = {"ms": acc[0] / k3[0], "launches_per_step": k3[0], "bytes": nb * 16.0 * C}

@@ -504,13 +504,18 @@ __global__ __launch_bounds__(LSS_THREADS) void ls_solve_kernel(LsSolveArgs a) {
         if (a.theta != 0.0 && k < a.peek) {
             const float2* rr = a.ref + (int64_t)b * a.ref_stride;
             const float2* ss = a.srv + (int64_t)b * a.srv_stride;
+            // phase of s~ at sample m+k: one sincos, then a one-sample rotation per term
+            double s2, c2;
+            sincos(-a.theta * (double)(a.n - a.peek + k + a.peek), &s2, &c2);
+            double2 ph = make_double2(c2, s2);
+            sincos(-a.theta, &s2, &c2);
+            const double2 dph = make_double2(c2, s2);
             for (int64_t m = a.n - a.peek; m + k < a.n; ++m) {
                 const float2 r = rr[m + a.peek - a.n];
                 const float2 sraw = ss[m + k];
-                double s2, c2;
-                sincos(-a.theta * (double)(m + k + a.peek), &s2, &c2);
-                const double2 st = zmul(make_double2(sraw.x, sraw.y), make_double2(c2, s2));
+                const double2 st = zmul(make_double2(sraw.x, sraw.y), ph);
                 eb = zadd(eb, zmul(make_double2(r.x, -r.y), st));
+                ph = zmul(ph, dph);
             }
         }
         const double2 rhs = zmul(D, zadd(make_double2(br, -bi), zmul(make_double2(gx, -gy), eb)));

@@ -23,11 +23,6 @@ import numpy as np
 __all__ = ["Shard", "plan_shard", "gather_frames", "HipBackend", "StreamProcessor"]
 
 
-def C_void(ptr):
-    import ctypes
-    return ctypes.c_void_p(ptr)
-
-
 @dataclass(frozen=True)
 class Shard:
     rank: int
@@ -85,11 +80,16 @@ def gather_frames(local, shard, group=None, dst=0):
 
 
 class HipBackend:
-    """The compute of one shard on one MI355X: batched LS chunks + batched overlapped CAF frames."""
+    """The compute of one shard on one MI355X: batched LS chunks + batched overlapped CAF frames.
+
+    ``run`` software-pipelines the two stages over sub-batches on two HIP streams: while the LS
+    chain of sub-batch k+1 sits in its latency-bound solves (one Levinson-Durbin per block, a few
+    wavefronts busy), the VALU-bound CAF kernel of sub-batch k fills the chip.
+    """
 
     def __init__(self, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
                  doppler_bins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), clutter="ls",
-                 batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, ls_streams=2):
+                 batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, overlap=True):
         import torch
         from . import engine
         from .range_doppler_processing import _named_window
@@ -104,26 +104,19 @@ class HipBackend:
         self.batch = int(batch)
         self.nlms_mu = float(nlms_mu)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        # pipelining doubles the latency-bound solve launches; it only pays once they are amortised
+        self.overlap = bool(overlap) and clutter == "ls" and self.batch >= 128
+        self.sub = -(-self.batch // 2) if self.overlap else self.batch     # chunks per LS launch
         with torch.cuda.device(self.device):
             self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch, caf_method, doppler_method)
-            self.ls = None
-            self.ls_lanes = []
-            if clutter == "ls":
-                # The Levinson solve of a batch occupies <= batch wavefronts for ~T sequential
-                # steps; two half-batches on two HIP streams let one half's solve hide under the
-                # other half's correlation / FIR kernels.
-                self.nlanes = 2 if self.batch >= 8 and ls_streams >= 2 else 1
-                per = -(-self.batch // self.nlanes)
-                for _ in range(self.nlanes):
-                    self.ls_lanes.append((engine.LsPlan(self.C, self.R, 10, False, per),
-                                          torch.cuda.Stream(device=self.device)))
-                self.ls = self.ls_lanes[0][0]
-                self.ls_per = per
+            self.ls = engine.LsPlan(self.C, self.R, 10, False, self.sub) if clutter == "ls" else None
             if isinstance(window, (tuple, str)):
                 w = _named_window(window, self.cpi)
             else:
                 w = None if window is None else np.ascontiguousarray(window, dtype=np.float32)
             self.window = None if w is None else torch.from_numpy(w).to(self.device)
+            self.s_ls = torch.cuda.Stream(device=self.device) if self.overlap else None
+            self.s_caf = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._clean_buf = None
 
     def _stream(self):
@@ -139,55 +132,79 @@ class HipBackend:
         buf[self.C // 2:self.C // 2 + n].copy_(t, non_blocking=True)
         return buf
 
+    def _clean_target(self, srv_pad):
+        # the cleaned stream buffer is reused across calls; only its two C/2 pads must be zero and
+        # the kernels never write them
+        out = self._clean_buf
+        if out is None or out.shape != srv_pad.shape or out.device != srv_pad.device:
+            out = self._clean_buf = self.torch.zeros_like(srv_pad)
+        return out
+
+    def _clean_range(self, ref_pad, srv_pad, out, c0, nb, stream):
+        C, off = self.C, self.C // 2 + c0 * self.C
+        if self.clutter == "ls":
+            self.ls.execute(ref_pad[off:], srv_pad[off:], out[off:], nb, C, C, self.fs, self.bins, 0.0,
+                            None, stream)
+        else:
+            self.engine.nlms_execute(ref_pad[off:], srv_pad[off:], out[off:], C, self.R, self.nlms_mu, 10,
+                                     None, None, nb, C, C, stream)
+
     def clean(self, ref_pad, srv_pad, nlocal):
         """LS_Filter_Multiple / NLMS per chunk, chunk c of the padded stream -> same place in the
         returned padded cleaned stream (main.py:169-176)."""
-        torch = self.torch
-        C, h = self.C, self.C // 2
         if self.clutter is None:
             return srv_pad
-        # cleaned stream buffer is reused across calls; only its two C/2 pads must be zero and the
-        # kernels never write them
-        out = self._clean_buf
-        if out is None or out.shape != srv_pad.shape or out.device != srv_pad.device:
-            out = self._clean_buf = torch.zeros_like(srv_pad)
-        with torch.cuda.device(self.device):
-            for c0 in range(0, nlocal, self.batch):
-                nb = min(self.batch, nlocal - c0)
-                off = h + c0 * C
-                if self.clutter == "ls" and self.nlanes == 1:
-                    self.ls.execute(ref_pad[off:], srv_pad[off:], out[off:], nb, C, C, self.fs,
-                                    self.bins, 0.0, None, self._stream())
-                elif self.clutter == "ls":
-                    main = torch.cuda.current_stream()
-                    done = []
-                    for li, (plan, st) in enumerate(self.ls_lanes):
-                        b0 = li * self.ls_per
-                        nl = min(self.ls_per, nb - b0)
-                        if nl <= 0:
-                            break
-                        st.wait_stream(main)
-                        o2 = off + b0 * C
-                        plan.execute(ref_pad[o2:], srv_pad[o2:], out[o2:], nl, C, C, self.fs,
-                                     self.bins, 0.0, None, C_void(st.cuda_stream))
-                        done.append(st)
-                    for st in done:
-                        main.wait_stream(st)
-                else:
-                    self.engine.nlms_execute(ref_pad[off:], srv_pad[off:], out[off:], C, self.R,
-                                             self.nlms_mu, 10, None, None, nb, C, C, self._stream())
+        out = self._clean_target(srv_pad)
+        step = self.sub if self.clutter == "ls" else self.batch
+        with self.torch.cuda.device(self.device):
+            for c0 in range(0, nlocal, step):
+                self._clean_range(ref_pad, srv_pad, out, c0, min(step, nlocal - c0), self._stream())
         return out
 
-    def frames(self, ref_pad, clean_pad, offsets_first, nframes):
-        """fast_xambg on nframes overlapped frames starting at element offset offsets_first (stride C)."""
+    def frames(self, ref_pad, clean_pad, offsets_first, nframes, out=None, f_lo=0, f_hi=None, stream=None):
+        """fast_xambg on overlapped frames [f_lo, f_hi) (stride C; frame 0 at element offsets_first)."""
         torch = self.torch
-        out = torch.empty((nframes, self.F, self.R + 1), dtype=torch.complex64, device=self.device)
+        if out is None:
+            out = torch.empty((nframes, self.F, self.R + 1), dtype=torch.complex64, device=self.device)
+        f_hi = nframes if f_hi is None else f_hi
         with torch.cuda.device(self.device):
-            for f0 in range(0, nframes, self.batch):
-                nb = min(self.batch, nframes - f0)
+            for f0 in range(f_lo, f_hi, self.batch):
+                nb = min(self.batch, f_hi - f0)
                 off = offsets_first + f0 * self.C
                 self.caf.execute(ref_pad[off:], clean_pad[off:], out[f0:], nb, self.C, self.cpi,
-                                 self.window, self._stream())
+                                 self.window, self._stream() if stream is None else stream)
+        return out
+
+    def run(self, ref_pad, srv_pad, nlocal, offsets_first, nframes):
+        """clean + frames for one resident shard.  With ``overlap`` the LS chain runs sub-batch by
+        sub-batch on one stream and the CAF of every frame whose three chunks are already clean
+        follows on a second stream (frame j needs local chunk j + offsets_first/C + 1)."""
+        if not self.overlap or nlocal <= self.sub:
+            clean = self.clean(ref_pad, srv_pad, nlocal)
+            return self.frames(ref_pad, clean, offsets_first, nframes)
+        import ctypes
+        torch = self.torch
+        clean = self._clean_target(srv_pad)
+        out = torch.empty((nframes, self.F, self.R + 1), dtype=torch.complex64, device=self.device)
+        main = torch.cuda.current_stream()
+        self.s_ls.wait_stream(main)
+        self.s_caf.wait_stream(main)
+        first_chunk = offsets_first // self.C
+        done = 0
+        with torch.cuda.device(self.device):
+            for c0 in range(0, nlocal, self.sub):
+                c1 = min(c0 + self.sub, nlocal)
+                self._clean_range(ref_pad, srv_pad, clean, c0, c1 - c0, ctypes.c_void_p(self.s_ls.cuda_stream))
+                ev = torch.cuda.Event()
+                ev.record(self.s_ls)
+                ready = nframes if c1 == nlocal else max(min(nframes, c1 - 1 - first_chunk), 0)
+                if ready > done:
+                    self.s_caf.wait_event(ev)
+                    self.frames(ref_pad, clean, offsets_first, nframes, out, done, ready,
+                                ctypes.c_void_p(self.s_caf.cuda_stream))
+                    done = ready
+        main.wait_stream(self.s_ls)
+        main.wait_stream(self.s_caf)
         return out
 
 
@@ -216,8 +233,11 @@ class StreamProcessor:
         lo, hi = sh.chunk_lo * C, sh.chunk_hi * C
         ref_pad = self.backend.padded(ref[lo:hi])
         srv_pad = self.backend.padded(srv[lo:hi])
-        clean_pad = self.backend.clean(ref_pad, srv_pad, sh.nlocal_chunks)
-        frames = self.backend.frames(ref_pad, clean_pad, sh.frame_offset(sh.frame_lo, C), sh.nframes)
+        if hasattr(self.backend, "run"):
+            frames = self.backend.run(ref_pad, srv_pad, sh.nlocal_chunks, sh.frame_offset(sh.frame_lo, C), sh.nframes)
+        else:
+            clean_pad = self.backend.clean(ref_pad, srv_pad, sh.nlocal_chunks)
+            frames = self.backend.frames(ref_pad, clean_pad, sh.frame_offset(sh.frame_lo, C), sh.nframes)
         return frames, sh
 
     def process(self, ref, srv, gather=True):
