@@ -224,7 +224,8 @@ def main():
             try:
                 traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
                 if traffic is not None:
-                    traffic = traffic * B          # file holds bytes per chunk/frame; one launch covers B
+                    # file holds bytes per chunk/frame; an LS launch covers one sub-batch, a CAF launch B frames
+                    traffic = traffic * (min(B, be.sub) if dom.startswith("ls_") else B)
             except Exception:
                 traffic = None
         per_frame_bytes = 20.0 * n + 8.0 * F * (R + 1) + (200.0 * C if clutter == "ls" else
@@ -235,12 +236,13 @@ def main():
                       if args.workload == "cfg2" else f"CAF frames/sec ({args.workload})",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "c64 (f32 arithmetic; f64 Levinson solve)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: Fs={fs:g} N={n} R={R} F={F} clutter="
                                    f"{clutter or 'none'}{' x5 Doppler bins, T=%d' % (R + 10) if clutter == 'ls' else ''}, "
                                    f"{B} overlapped frames/GPU/step (hop N/2), Kaiser(5) window",
                        "frames_per_gpu_per_step": B,
+                       "arithmetic": "complex64 streams, f32 FFT butterflies, f64 Levinson-Durbin / tap solves",
                        "caf_method": {1: "direct", 2: "fft"}.get(m, m),
                        "doppler_method": {1: "rocfft", 2: "fused"}.get(dp, dp),
                        "parallelism": f"frame-sharded x{world}, RCCL gather of maps" if world > 1 else "single GPU"},

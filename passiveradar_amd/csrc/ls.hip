@@ -7,8 +7,9 @@
 //      (scipy.signal.correlate 'valid' at :142-147), r = peek-rotated, phase-rotated reference
 //      generated on the fly while staging LDS (the reference materialises roll() and
 //      frequency_shift() arrays);
-//   2. levinson_kernel     : fp64 reduction of the partials + Hermitian-Toeplitz Levinson solve
-//      (scipy.linalg.solve_toeplitz at :150, complex128);
+//   2. levinson_wave_kernel: fp64 reduction of the partials + Hermitian-Toeplitz Levinson solve on one
+//      wavefront (scipy.linalg.solve_toeplitz at :150, complex128); the multi-bin chain on long
+//      blocks replaces it by ONE Levinson-Durbin per block + parallel per-bin solves (see below);
 //   3. fir_subtract_kernel : out = s - conv(r, w)[0:N] (np.convolve at :153-155), complex64.
 // With circular=1 the same kernels wrap indices modulo N, which is LS_Filter's circulant data
 // matrix: A^H A is exactly the circular-autocorrelation Toeplitz matrix, so no N x T matrix and
@@ -159,91 +160,6 @@ static int launch_corr(const CorrArgs& a, bool dual, int nbatch, hipStream_t str
 #undef PRC_CORR_CASE
     PRC_LAUNCH_CHECK();
     return PRC_OK;
-}
-
-// ---- Levinson (fp64) ------------------------------------------------------------------
-// LDS: c[T], bb[T], a0[T], a1[T], w[T] (double2) + 8 double2 of reduction scratch.
-__device__ __forceinline__ double2 wave_sum_z(double2 v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        v.x += __shfl_down(v.x, off, 64);
-        v.y += __shfl_down(v.y, off, 64);
-    }
-    return v;
-}
-
-__global__ __launch_bounds__(LS_THREADS) void levinson_kernel(const float2* __restrict__ partial,
-                                                              int nblk, int T, double reg,
-                                                              double2* __restrict__ taps_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double2* c = reinterpret_cast<double2*>(smem_raw);
-    double2* bb = c + T;
-    double2* abuf0 = bb + T;
-    double2* abuf1 = abuf0 + T;
-    double2* w = abuf1 + T;
-    double2* red = w + T;  // [2][4]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    const float2* part = partial + (int64_t)b * nblk * 2 * T;
-
-    // c[k] = conj(sum_blk partial_rr[k]),  bb[k] = conj(sum_blk partial_rs[k])   (fp64 sums)
-    for (int k = tid; k < T; k += LS_THREADS) {
-        double cr = 0, ci = 0, br = 0, bi = 0;
-        for (int blk = 0; blk < nblk; ++blk) {
-            const float2 u = part[((int64_t)blk * 2 + 0) * T + k];
-            const float2 v = part[((int64_t)blk * 2 + 1) * T + k];
-            cr += (double)u.x; ci += (double)u.y;
-            br += (double)v.x; bi += (double)v.y;
-        }
-        if (k == 0) cr += reg;
-        c[k] = make_double2(cr, -ci);
-        bb[k] = make_double2(br, -bi);
-        abuf0[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
-        abuf1[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
-        w[k] = make_double2(0.0, 0.0);
-    }
-    __syncthreads();
-    double err = c[0].x;
-    if (tid == 0) w[0] = zdiv(bb[0], c[0]);
-    __syncthreads();
-
-    double2* a_old = abuf0;
-    double2* a_new = abuf1;
-    for (int m = 1; m < T; ++m) {
-        double2 acc = make_double2(0, 0), dot = make_double2(0, 0);
-        for (int i = tid; i < m; i += LS_THREADS) {
-            const double2 cm = c[m - i];
-            acc = zadd(acc, zmul(a_old[i], cm));
-            dot = zadd(dot, zmul(cm, w[i]));
-        }
-        acc = wave_sum_z(acc);
-        dot = wave_sum_z(dot);
-        if (lane == 0) {
-            red[wave] = acc;
-            red[4 + wave] = dot;
-        }
-        __syncthreads();
-        acc = zadd(zadd(red[0], red[1]), zadd(red[2], red[3]));
-        dot = zadd(zadd(red[4], red[5]), zadd(red[6], red[7]));
-        const double2 k = make_double2(-acc.x / err, -acc.y / err);
-        err = err * (1.0 - (k.x * k.x + k.y * k.y));
-        const double2 res = zsub(bb[m], dot);
-        const double2 g = make_double2(res.x / err, res.y / err);
-        // a_new[j] = a_old[j] + k conj(a_old[m-j]);  w[j] += g conj(a_new[m-j]),
-        // with a_new[m-j] = a_old[m-j] + k conj(a_old[j])  (a_old[m] == 0)
-        for (int j = tid; j <= m; j += LS_THREADS) {
-            const double2 aj = a_old[j];
-            const double2 amj = a_old[m - j];
-            a_new[j] = zadd(aj, zmul(k, zconj(amj)));
-            const double2 anew_mj = zadd(amj, zmul(k, zconj(aj)));
-            w[j] = zadd(w[j], zmul(g, zconj(anew_mj)));
-        }
-        __syncthreads();
-        double2* t = a_old;
-        a_old = a_new;
-        a_new = t;
-    }
-    for (int k = tid; k < T; k += LS_THREADS) taps_out[(int64_t)b * T + k] = w[k];
 }
 
 // ---- Levinson on ONE wavefront (no workgroup barrier on the T-step critical path) -------------
@@ -688,7 +604,7 @@ extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
     return PRC_OK;
 }
 
-static size_t levinson_lds(int T) { return sizeof(double2) * ((size_t)5 * T + 8); }
+static size_t levinson_lds(int T) { return sizeof(double2) * ((size_t)5 * T); }
 static size_t fir_lds(int T) { return sizeof(float2) * ((size_t)T + FIR_SPAN + T - 1); }
 
 extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
@@ -716,9 +632,6 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     if (e == hipSuccess) e = hipMalloc(&p->d_taps, sizeof(double2) * (size_t)d->max_blocks * T);
     if (e == hipSuccess) e = hipMalloc(&p->d_tmp[0], sizeof(float2) * (size_t)d->max_blocks * d->n);
     if (e == hipSuccess) e = hipMalloc(&p->d_tmp[1], sizeof(float2) * (size_t)d->max_blocks * d->n);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)levinson_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
     if (e == hipSuccess && p->method == 2 && !d->circular) {
         e = hipMalloc(&p->d_c0, sizeof(double2) * (size_t)d->max_blocks * T);
         if (e == hipSuccess) e = hipMalloc(&p->d_se, sizeof(double2) * (size_t)d->max_blocks * T);

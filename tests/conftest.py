@@ -41,6 +41,16 @@ CAF_SMALL = ["p2", "p2_kaiser_arr", "p2_kaiser_tuple", "oddq", "oddq_p1", "nondi
              "bigq", "padded", "longfilt", "srv128", "lags_gt_q"]
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The C-ABI library is a build product (git-ignored): build it once if it is missing."""
+    from passiveradar_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    yield
+
+
 @pytest.fixture(scope="session")
 def gpu_ready():
     from passiveradar_amd import _lib
