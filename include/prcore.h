@@ -112,7 +112,9 @@ typedef struct prc_ls_desc {
                               linear correlations, linear FIR); 1: LS_Filter semantics (:6-56:
                               circular data matrix => circular correlations and FIR)        */
     int32_t max_blocks;    /* workspace is sized for this many independent blocks           */
-    int32_t method;        /* 0 auto, 1 direct (time-domain), 2 FFT overlap-save            */
+    int32_t method;        /* 0 auto (= 3 when it fits), 1 time-domain kernels, 2 FFT kernels that
+                              recompute the reference spectra per Doppler bin, 3 FFT kernels with
+                              the reference spectra cached in HBM between Doppler bins       */
 } prc_ls_desc;
 
 typedef struct prc_ls_plan prc_ls_plan;

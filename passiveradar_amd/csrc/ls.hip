@@ -611,6 +611,7 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     PRC_REQUIRE(plan && d, PRC_EINVAL, "prc_ls_plan_create: null argument");
     PRC_REQUIRE(d->n > 0 && d->filter_len > 0 && d->peek >= 0 && d->max_blocks > 0, PRC_EINVAL,
                 "prc_ls_plan_create: non-positive size");
+    PRC_REQUIRE(d->method >= 0 && d->method <= 3, PRC_EINVAL, "prc_ls_plan_create: method %d", d->method);
     const int T = d->filter_len + d->peek;
     PRC_REQUIRE(T < d->n, PRC_EINVAL, "prc_ls_plan_create: filter_len+peek (%d) >= n (%lld)", T,
                 (long long)d->n);
@@ -621,6 +622,7 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     p->T = T;
     p->method = d->method;
     if (p->method == 0) p->method = ls_fft_supported(T) ? 2 : 1;
+    if (p->method == 3) p->method = 2;          // same kernels; d->method == 3 only adds the spectrum cache
     if (p->method == 2 && !ls_fft_supported(T)) {
         prc_set_error("prc_ls_plan_create: FFT method supports at most 769 taps, got %d", T);
         delete p;
@@ -637,8 +639,15 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
         if (e == hipSuccess) e = hipMalloc(&p->d_se, sizeof(double2) * (size_t)d->max_blocks * T);
         if (e == hipSuccess) e = hipMalloc(&p->d_tinv, sizeof(double2) * (size_t)d->max_blocks * T * T);
         if (e == hipSuccess) e = hipMalloc(&p->d_taps_t, sizeof(double2) * (size_t)d->max_blocks * T);
-        if (e == hipSuccess)
-            e = hipMalloc(&p->d_cache, sizeof(float2) * (size_t)d->max_blocks * ls_cache_elems_per_block(d->n, T));
+        // auto / method 3: keep FFT(rho block) in an HBM spectrum cache instead of recomputing it per
+        // bin (measured: the fused kernel is HBM-bound at 2 FFTs per block and VALU-bound at 3).  If the
+        // cache does not fit, the chain silently recomputes.
+        if (e == hipSuccess && d->method != 2) {
+            if (hipMalloc(&p->d_cache, sizeof(float2) * (size_t)d->max_blocks * ls_cache_elems_per_block(d->n, T)) != hipSuccess) {
+                p->d_cache = nullptr;
+                (void)hipGetLastError();
+            }
+        }
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)ls_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)

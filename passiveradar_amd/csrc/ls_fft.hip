@@ -553,9 +553,11 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 1) void ls_corr_cached_kernel(LsFft
             }
             __builtin_amdgcn_sched_barrier(0);
             fft1024_fwd(x, tile, tab, f);
-            float2* __restrict__ cp = cache + (int64_t)p * FFTW_P;
+            if (a.cache) {
+                float2* __restrict__ cp = cache + (int64_t)p * FFTW_P;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cp[64 * r + lane] = x[r];
+                for (int r = 0; r < 16; ++r) cp[64 * r + lane] = x[r];
+            }
             fft1024_fwd(up, tile, tab, f);
 #pragma unroll
             for (int m = 0; m < 16; ++m) cmac_bconj(wrr[m], up[m], x[m]);
@@ -594,6 +596,10 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 1) void ls_corr_cached_kernel(LsFft
 // wave reads X_p (cache) and the surveillance piece once, writes the cleaned piece once and keeps it
 // in registers as the input of the next bin's correlation -- 20 KB of HBM traffic per 1025-T
 // samples per bin instead of 34 KB for the two separate kernels.
+// CACHED: X_p = FFT(rho block p) is read from the spectrum cache (8 KB per block).  !CACHED: it is
+// recomputed from the reference (6 KB per block + L2-served overlap, one more FFT): fewer HBM bytes,
+// more VALU -- the kernel is HBM-bound, so this is the default.
+template <bool CACHED>
 __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
@@ -633,13 +639,21 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
 #pragma unroll
     for (int m = 0; m < 16; ++m) wrs[m] = make_float2(0.f, 0.f);
 
+    const __amdgpu_buffer_rsrc_t rx = prc_rsrc(ref + peek, lsf_clampu(n - peek) * 8u);
     float2 xn[16];
     auto issue_x = [&](int p) {
         const bool live = p < nblocks;
-        const __amdgpu_buffer_rsrc_t rc = prc_rsrc(cache + (int64_t)(live ? p : 0) * FFTW_P,
-                                                   live ? FFTW_P * 8u : 0u);
+        if (CACHED) {
+            const __amdgpu_buffer_rsrc_t rc = prc_rsrc(cache + (int64_t)(live ? p : 0) * FFTW_P,
+                                                       live ? FFTW_P * 8u : 0u);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rc, vo8, 512u * r);
+            for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rc, vo8, 512u * r);
+        } else {
+            const int mstart = (live ? p * B : n) - ext;
+            const unsigned voff = vo8 + (unsigned)mstart * 8u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rx, voff + 512u * r, 0u);
+        }
     };
     issue_x(wg);
     for (int p = wg; p < nblocks; p += nwaves) {
@@ -647,7 +661,27 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
         const int cnt = (n - n0) < B ? (n - n0) : B;
         float2 xc[16], y[16], sv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { xc[r] = xn[r]; y[r] = cmul(xn[r], h[r]); }
+        for (int r = 0; r < 16; ++r) xc[r] = xn[r];
+        if (!CACHED) {
+            // wrapped tail of rho (source index restarts at ref[0]); unrotated, so no phase here
+            const int wstart = n - peek - (n0 - ext);
+            if (peek > 0 && wstart < FFTW_P) {
+                int cw = FFTW_P - wstart;
+                if (cw > peek) cw = peek;
+                const __amdgpu_buffer_rsrc_t rw = prc_rsrc(ref, lsf_clampu(cw) * 8u);
+                const unsigned voff = vo8 - (unsigned)wstart * 8u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float2 w = prc_buf_load_c64(rw, voff + 512u * r, 0u);
+                    xc[r].x += w.x;
+                    xc[r].y += w.y;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fft1024_fwd(xc, tile, tab, f);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = cmul(xc[r], h[r]);
         __builtin_amdgcn_sched_barrier(0);
         issue_x(p + nwaves);
         {
@@ -806,7 +840,10 @@ int ls_launch_fused_cached(LsFftArgs a, double theta, double theta_next, double 
     if (rc) return rc;
     dim3 grid((unsigned)(waves_per_block / LSF_WAVES), (unsigned)nblocks);
     const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE);
-    hipLaunchKernelGGL(ls_fused_cached_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    if (a.cache)
+        hipLaunchKernelGGL(ls_fused_cached_kernel<true>, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    else
+        hipLaunchKernelGGL(ls_fused_cached_kernel<false>, grid, dim3(64 * LSF_WAVES), lds, stream, a);
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }

@@ -89,7 +89,8 @@ class HipBackend:
 
     def __init__(self, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
                  doppler_bins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), clutter="ls",
-                 batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, overlap=True):
+                 batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, overlap=True,
+                 ls_method=0):
         import torch
         from . import engine
         from .range_doppler_processing import _named_window
@@ -109,7 +110,7 @@ class HipBackend:
         self.sub = -(-self.batch // 2) if self.overlap else self.batch     # chunks per LS launch
         with torch.cuda.device(self.device):
             self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch, caf_method, doppler_method)
-            self.ls = engine.LsPlan(self.C, self.R, 10, False, self.sub) if clutter == "ls" else None
+            self.ls = engine.LsPlan(self.C, self.R, 10, False, self.sub, ls_method) if clutter == "ls" else None
             if isinstance(window, (tuple, str)):
                 w = _named_window(window, self.cpi)
             else:

@@ -76,11 +76,12 @@ def test_caf_cfg3_digest():
     assert np.abs(out.sum(axis=1) - g["row_sums"]).max() / (peak * np.sqrt(R + 1)) < TOL
 
 
-@pytest.fixture(params=["direct", "fft"])
+@pytest.fixture(params=["direct", "fft", "fft_cached"])
 def ls_method(request):
-    """run every LS case through both kernel families (time-domain LDS tiles / wavefront FFT)"""
+    """run every LS case through every kernel family (time-domain LDS tiles / wavefront FFT with the
+    reference spectra recomputed per bin / kept in an HBM cache)"""
     from passiveradar_amd import clutter_removal as cr
-    cr.set_default_ls_method({"direct": 1, "fft": 2}[request.param])
+    cr.set_default_ls_method({"direct": 1, "fft": 2, "fft_cached": 3}[request.param])
     yield request.param
     cr.set_default_ls_method(0)
 
