@@ -205,10 +205,14 @@ def main():
             nb = min(B, be.sub)                                # blocks behind one LS launch
             T = R + 10
             fused = k3[0] == 1 and k3[2] > 1                   # cached-spectrum chain: corr(i+1) inside FIR(i)
+            nsub = -(-B // nb)                                 # LS executes (sub-batches) per step
+            k3 = tuple(k * nsub for k in k3)
+            acc = acc * nsub
             kt["ls_correlate"] = {"ms": acc[0] / k3[0], "launches_per_step": k3[0], "bytes": nb * 16.0 * C}
             kt["ls_solve"] = {"ms": acc[1] / k3[1], "launches_per_step": k3[1],
                               "bytes": nb * (T * T * 16.0 + 64 * 2 * T * 8.0)}
-            fir_bytes = 24.0 * C + (16.0 * C * (k3[2] - 1) / k3[2] if fused else 0.0)
+            nb_bins = k3[2] // nsub
+            fir_bytes = 24.0 * C + (16.0 * C * (nb_bins - 1) / nb_bins if fused else 0.0)
             kt["ls_fir_subtract"] = {"ms": acc[2] / k3[2], "launches_per_step": k3[2], "bytes": nb * fir_bytes}
         elif clutter == "nlms":
             a, b = ev(), ev()
