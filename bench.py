@@ -38,7 +38,10 @@ WORKLOADS = {
     "cfg2p2": (2.4e6, 2097152, 256, 512, "ls"),
     "cfg1": (262184.87, 262144, 256, 256, "ls"),
     "cfg3": (1.0e7, 5000000, 1024, 1024, "nlms"),
+    # config 5: 20 MS/s, 2048 x 2048, four illuminators against one surveillance channel, CAF only
+    "cfg5": (2.0e7, 1 << 23, 2048, 2048, None),
 }
+N_ILLUMINATORS = {"cfg5": 4}
 
 
 def synth_stream(torch, nchunks, C, fs, R, seed, device):
@@ -140,10 +143,14 @@ def main():
     ref_pad = be.padded(ref)
     srv_pad = be.padded(srv)
     del ref, srv
+    nill = N_ILLUMINATORS.get(args.workload, 1)
+    extra_refs = [be.padded(synth_stream(torch, B, C, fs, R, 777 + 13 * i + rank, device)[0]) for i in range(nill - 1)]
     shard = prstream.Shard(rank, world, B * world, rank * B, (rank + 1) * B, 0, B)
 
     def step():
         frames = be.run(ref_pad, srv_pad, B, 0, B)
+        for er in extra_refs:                      # further illuminators share the surveillance channel
+            be.run(er, srv_pad, B, 0, B)
         if world > 1:
             return prstream.gather_frames(frames, shard)
         return frames
@@ -165,7 +172,7 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    frames_total = B * world * args.steps
+    frames_total = B * world * args.steps          # a multi-illuminator frame = all its CAF surfaces
     value = frames_total / dt
 
     # ---- per-kernel timing with HIP events on the launch stream (rank 0) --------------------
