@@ -720,8 +720,14 @@ static int run_cached_chain(prc_ls_plan* p, const void* ref, const void* srv, in
         sa.n = n;  sa.nblk = p->nblk;  sa.T = T;  sa.peek = p->desc.peek;
         // effective slope of the reference's float32 ramp: fl32(2 pi f) * fl32(1/Fs)
         sa.theta = pr.enabled ? (double)pr.a32 * (double)pr.rcp32 : 0.0;
-        // one refinement squares the wrap perturbation (~ a few peek/N); two for shorter blocks
-        sa.nref = !pr.enabled ? 0 : (n >= 100000LL * (p->desc.peek > 0 ? p->desc.peek : 1) ? 1 : 2);
+        // one refinement squares the wrap perturbation (~ a few peek/N); two for shorter blocks; none
+        // when the ramp closes on itself over the block (gamma = e^{-j theta N} = 1: c_f = D c_0 exactly)
+        const double gm1 = hypot(cos(sa.theta * (double)n) - 1.0, sin(sa.theta * (double)n));
+        // relative size of the perturbation (gamma-1) S_e against c_0: ~ |gamma-1| * 10 peek / N;
+        // k refinement steps leave ~ est^(k+1)
+        const double est = pr.enabled ? gm1 * 10.0 * (double)p->desc.peek / (double)n : 0.0;
+        sa.nref = 0;
+        for (double left = est; left > 1e-9 && sa.nref < 4; left *= est) ++sa.nref;
         hipLaunchKernelGGL(ls_solve_kernel, dim3(nblocks), dim3(LSS_THREADS), solve_lds, stream, sa);
         PRC_LAUNCH_CHECK();
         return PRC_OK;
