@@ -147,15 +147,30 @@ def main():
     extra_refs = [be.padded(synth_stream(torch, B, C, fs, R, 777 + 13 * i + rank, device)[0]) for i in range(nill - 1)]
     shard = prstream.Shard(rank, world, B * world, rank * B, (rank + 1) * B, 0, B)
 
+    pending = []                                   # (frames kept alive, result, work) of the gather in flight
+
+    def drain():
+        while pending:
+            _, _, work = pending.pop()
+            if work is not None:
+                work.wait()
+
     def step():
         frames = be.run(ref_pad, srv_pad, B, 0, B)
         for er in extra_refs:                      # further illuminators share the surveillance channel
             be.run(er, srv_pad, B, 0, B)
         if world > 1:
-            return prstream.gather_frames(frames, shard)
+            # the only collective: gather of this step's maps to rank 0 (RCCL over xGMI), issued
+            # asynchronously so that it overlaps the next step's kernels; every gather is complete
+            # before the timed region closes (drain() in fence())
+            drain()
+            res, work = prstream.gather_frames(frames, shard, async_op=True)
+            pending.append((frames, res, work))
+            return res
         return frames
 
     def fence():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -57,26 +57,43 @@ def plan_shard(nchunks, rank=0, world=1):
     return Shard(rank, world, nchunks, lo, hi, max(lo - 1, 0), min(hi + 1, nchunks))
 
 
-def gather_frames(local, shard, group=None, dst=0):
+_gather_buffers = {}
+
+
+def gather_frames(local, shard, group=None, dst=0, async_op=False):
     """Gather per-rank frame blocks [m_r][F][R+1] (torch tensors, complex64) to rank ``dst``.
-    Returns the full [nchunks][F][R+1] tensor on dst, None elsewhere.  Single collective."""
+    Returns the full [nchunks][F][R+1] tensor on dst, None elsewhere.  ONE collective; complex
+    tensors travel as float pairs (RCCL has no complex dtype) without a staging copy when the shard
+    is full-size, and land directly in slices of one preallocated result buffer on dst.
+
+    async_op=True returns ``(result_or_None, work)``: the gather runs on the communication stream
+    while the caller computes the next batch; ``work.wait()`` before touching the result."""
     import torch
     import torch.distributed as dist
     if shard.world == 1:
-        return local
+        return (local, None) if async_op else local
     per = -(-shard.nchunks // shard.world)
     F, cols = local.shape[1], local.shape[2]
-    # complex tensors go over the wire as float pairs (RCCL has no complex dtype)
-    send = torch.zeros((per, F, cols, 2), dtype=torch.float32, device=local.device)
-    if shard.nframes:
-        send[:shard.nframes] = torch.view_as_real(local)
+    if shard.nframes == per and local.is_contiguous():
+        send = torch.view_as_real(local)
+    else:
+        send = torch.zeros((per, F, cols, 2), dtype=torch.float32, device=local.device)
+        if shard.nframes:
+            send[:shard.nframes] = torch.view_as_real(local)
     if dist.get_rank(group) == dst:
-        recv = [torch.empty_like(send) for _ in range(shard.world)]
-        dist.gather(send, recv, dst=dst, group=group)
-        full = torch.view_as_complex(torch.cat(recv, dim=0).contiguous())
-        return full[:shard.nchunks]
-    dist.gather(send, None, dst=dst, group=group)
-    return None
+        key = (shard.world, per, F, cols, str(local.device))
+        full = _gather_buffers.get(key)
+        if full is None or async_op:
+            # a fresh buffer per in-flight async gather; a cached one for the blocking form
+            full = torch.empty((shard.world * per, F, cols, 2), dtype=torch.float32, device=local.device)
+            if not async_op:
+                _gather_buffers[key] = full
+        recv = [full[r * per:(r + 1) * per] for r in range(shard.world)]
+        work = dist.gather(send, recv, dst=dst, group=group, async_op=async_op)
+        res = torch.view_as_complex(full)[:shard.nchunks]
+        return (res, work) if async_op else res
+    work = dist.gather(send, None, dst=dst, group=group, async_op=async_op)
+    return (None, work) if async_op else None
 
 
 class HipBackend:
@@ -229,8 +246,10 @@ class StreamProcessor:
         C = self.backend.C
         nchunks = int(ref.shape[0]) // C
         sh = plan_shard(nchunks, self.rank, self.world)
-        if sh.nframes == 0:
-            return self.backend.frames_empty() if hasattr(self.backend, "frames_empty") else None, sh
+        if sh.nframes == 0:         # more ranks than frames: an empty block still takes part in the gather
+            import torch
+            return torch.zeros((0, self.backend.F, self.backend.R + 1), dtype=torch.complex64,
+                               device=getattr(self.backend, "device", "cpu")), sh
         lo, hi = sh.chunk_lo * C, sh.chunk_hi * C
         ref_pad = self.backend.padded(ref[lo:hi])
         srv_pad = self.backend.padded(srv[lo:hi])
@@ -246,10 +265,6 @@ class StreamProcessor:
         frames, sh = self.process_local(ref, srv)
         if self.world == 1 or not gather:
             return frames
-        if frames is None:
-            import torch
-            frames = torch.zeros((0, self.backend.F, self.backend.R + 1), dtype=torch.complex64,
-                                 device=getattr(self.backend, "device", "cpu"))
         return gather_frames(frames, sh, self.group)
 
     @staticmethod
