@@ -158,6 +158,41 @@ int prc_xcorr(const void* s1, const void* s2, int64_t n, int32_t nlead, int32_t 
 int prc_frequency_shift(const void* x, void* y, int64_t n, double fc, double fs,
                         double phase_offset, void* stream);
 
+/* ---- front end (SURVEY 8f "next" #1): main.py:105-166 per block ------------------------------ */
+typedef enum prc_raw_dtype {
+    PRC_RAW_I8 = 0, PRC_RAW_U8 = 1, PRC_RAW_I16 = 2, PRC_RAW_F32 = 3, /* interleaved I,Q scalars */
+    PRC_RAW_C64 = 4                                                   /* already complex64        */
+} prc_raw_dtype;
+
+typedef struct prc_frontend_desc {
+    int64_t n_in;          /* complex samples per block (= raw scalars / 2)                     */
+    int32_t raw_dtype;     /* prc_raw_dtype of the input                                         */
+    int32_t up, down;      /* rational resampling factor, already reduced by their gcd           */
+    int32_t ntaps;         /* length of taps_host                                                */
+    int32_t n_pre_remove;  /* resample_poly's output alignment: (half_len + n_pre_pad) / down    */
+    int32_t max_blocks;
+    const float* taps_host;/* HOST: firwin(20 max+1, 1/max, ('kaiser',5.0)) * up with n_pre_pad
+                              leading zeros (scipy.signal.resample_poly's h), copied at creation  */
+} prc_frontend_desc;
+
+typedef struct prc_frontend_plan prc_frontend_plan;
+int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_frontend_desc* desc);
+int prc_frontend_plan_destroy(prc_frontend_plan* plan);
+int prc_frontend_out_len(const prc_frontend_plan* plan, int64_t* n_out);   /* ceil(n_in*up/down) */
+/* deinterleave_IQ (signal_utils.py:19-22) -> frequency_shift(fc, fs, block phase) (:24-27 with the
+ * array phase of main.py:125-149; mix = 0 skips it) -> resample(up, down) (:15-17, padtype 'line'),
+ * fused; block b reads raw at b*raw_stride (elements of the raw type) and writes complex64 at
+ * b*out_stride.  phases_host: HOST array of nblocks block phase offsets (radians) or NULL. */
+int prc_frontend_execute(prc_frontend_plan* plan, const void* raw, int64_t raw_stride, int32_t mix,
+                         double fc, double fs, const double* phases_host, void* out, int64_t out_stride,
+                         int32_t nblocks, void* stream);
+/* deinterleave_IQ alone: n_complex pairs of raw scalars -> complex64 */
+int prc_deinterleave(const void* raw, int32_t raw_dtype, int64_t n_complex, void* out, void* stream);
+/* frequency_shift with an array (per-block) phase offset: complex64 in, complex128 out, float32 ramp
+ * + double block phase, as NumPy promotes it (signal_utils.py:24-27, main.py:133-149) */
+int prc_frequency_shift_block(const void* x, void* y, int64_t n, double fc, double fs,
+                              double block_phase, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,6 +199,31 @@ def stream_case():
          out=np.concatenate(frames, axis=2))
 
 
+def frontend_case():
+    """the front end of main.py:105-166 emulated around the reference's own
+    deinterleave_IQ / frequency_shift (array block phase) / resample."""
+    print("front end (deinterleave / block-phase tuning / 13:119 resampler)")
+    rng = np.random.Generator(np.random.Philox(key=scene.scene_seed(99)))
+    icl, nblk = 36000, 3                       # raw scalars per block (18000 complex samples)
+    fs, foff, up, dn = 2400000, 100000, 13, 119
+    raw8 = rng.integers(-100, 100, size=icl * nblk, dtype=np.int8)
+    mod_period = fs // foff
+    per_block = (icl // 2) % mod_period
+    phases = 2 * np.pi * np.arange(nblk) * per_block * (foff / fs)
+    outs, tuned1, deint1 = [], None, None
+    for i in range(nblk):
+        blk = ref_su.deinterleave_IQ(raw8[i * icl:(i + 1) * icl])
+        tuned = ref_su.frequency_shift(blk, foff, fs, np.array([phases[i]]))
+        if i == 1:
+            tuned1, deint1 = tuned, blk
+        outs.append(ref_su.resample(tuned, up, dn))
+    rawf = (rng.standard_normal(20001) * 3).astype(np.float32)          # odd length: last scalar dropped
+    save("frontend", raw8=raw8, icl=icl, fs=fs, foff=foff, up=up, dn=dn, phases=phases,
+         deint1=deint1, tuned1=tuned1, out=np.concatenate(outs),
+         rawf=rawf, deintf=ref_su.deinterleave_IQ(rawf),
+         res_c64=ref_su.resample(deint1, 3, 7), res_simple=ref_su.resample(deint1[:5000], 13, 119))
+
+
 def big_cases():
     print("big CAF cases (root finder short-circuited)")
     with no_root_finding():
@@ -248,5 +273,6 @@ if __name__ == "__main__":
         nlms_cases()
         config_cases()
         stream_case()
+        frontend_case()
     if args.big or args.only_big:
         big_cases()

@@ -387,3 +387,82 @@ def process_stream(ref, srv, cpi_samples, num_range_cells, num_doppler_cells, IF
     frames = [fast_xambg(a, b, num_range_cells, num_doppler_cells, cpi_samples, w)
               for a, b in zip(rf, sf)]
     return np.concatenate(frames, axis=2)
+
+
+# --------------------------------------------------------------------------
+# Front end (SURVEY 8f "next" #1): signal_utils.py:15-22 and main.py:105-166
+# --------------------------------------------------------------------------
+
+def deinterleave_IQ(interleavedIQ):
+    """signal_utils.py:19-22: [I0, Q0, I1, Q1, ...] scalars -> complex64 (a trailing odd scalar is dropped)."""
+    x = np.asarray(interleavedIQ)
+    n = x.shape[0] // 2
+    return (x[0:2 * n:2].astype(np.float64) + 1j * x[1:2 * n:2].astype(np.float64)).astype(np.complex64)
+
+
+def resample_design(up, dn):
+    """The FIR resample_poly designs for signal_utils.resample (signal_utils.py:15-17: window
+    ('kaiser', 5.0), 20*max(up,dn)+1 taps, cutoff 1/max(up,dn), gain up) and its alignment:
+    returns (h zero-padded in front, n_pre_remove)."""
+    from math import gcd
+    from scipy.signal import firwin
+    g = gcd(up, dn)
+    up, dn = up // g, dn // g
+    max_rate = max(up, dn)
+    half_len = 10 * max_rate
+    h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)) * up
+    n_pre_pad = dn - half_len % dn
+    n_pre_remove = (half_len + n_pre_pad) // dn
+    return np.concatenate((np.zeros(n_pre_pad), h)), n_pre_remove, up, dn
+
+
+def resample(x, up, dn):
+    """signal_utils.py:15-17: scipy.signal.resample_poly(x, up, dn, padtype='line') restated as a
+    polyphase sum:  y[m] = sum_j h[(t mod up) + up j] xe[t div up - j],  t = (m + n_pre_remove) dn,
+    xe = x extended linearly through its first and last sample (upfirdn mode 'line')."""
+    x = np.asarray(x)
+    hp, n_pre_remove, up, dn = resample_design(up, dn)
+    n_in = x.shape[0]
+    n_out = n_in * up
+    n_out = n_out // dn + bool(n_out % dn)
+    xd = x.astype(np.complex128 if np.iscomplexobj(x) else np.float64)
+    slope = (xd[-1] - xd[0]) / (n_in - 1)
+    J = -(-hp.size // up)
+    pad = J + 2
+    left = xd[0] + slope * np.arange(-pad, 0)
+    right = xd[-1] + slope * np.arange(1, pad + dn // up + 2)
+    xe = np.concatenate((left, xd, right))
+    t = (np.arange(n_out, dtype=np.int64) + n_pre_remove) * dn
+    phase = t % up
+    i0 = t // up + pad                      # index into xe
+    y = np.zeros(n_out, dtype=xd.dtype)
+    for p in range(up):
+        taps = hp[p::up]
+        sel = np.nonzero(phase == p)[0]
+        if sel.size == 0:
+            continue
+        # y[m] = sum_j taps[j] xe[i0 - j]  = (xe conv taps)[i0]
+        full = np.convolve(xe, taps)
+        y[sel] = full[i0[sel]]
+    return y.astype(x.dtype if np.issubdtype(x.dtype, np.inexact) else y.dtype)
+
+
+def block_phase_offsets(nblocks, input_chunk_length, input_sample_rate, offset_freq):
+    """main.py:125-130: starting phase of every block so that block-wise tuning is phase continuous."""
+    mod_period = input_sample_rate // offset_freq
+    per_block = (input_chunk_length // 2) % mod_period
+    return 2 * np.pi * np.arange(nblocks) * per_block * (offset_freq / input_sample_rate)
+
+
+def front_end(raw, input_chunk_length, offset_freq, input_sample_rate, up, dn):
+    """main.py:105-166 for one channel held in memory: per block of input_chunk_length raw scalars
+    deinterleave -> frequency_shift(offset_freq, block phase) -> resample(up, dn); blocks concatenated."""
+    raw = np.asarray(raw)
+    nblocks = raw.shape[0] // input_chunk_length
+    ph = block_phase_offsets(nblocks, input_chunk_length, input_sample_rate, offset_freq)
+    out = []
+    for i in range(nblocks):
+        blk = deinterleave_IQ(raw[i * input_chunk_length:(i + 1) * input_chunk_length])
+        tuned = frequency_shift(blk, offset_freq, input_sample_rate, np.array([ph[i]]))
+        out.append(resample(tuned, up, dn))
+    return np.concatenate(out)

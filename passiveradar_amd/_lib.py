@@ -37,6 +37,14 @@ class LsDesc(C.Structure):
                 ("circular", C.c_int32), ("max_blocks", C.c_int32), ("method", C.c_int32)]
 
 
+class FrontendDesc(C.Structure):
+    _fields_ = [("n_in", C.c_int64), ("raw_dtype", C.c_int32), ("up", C.c_int32), ("down", C.c_int32),
+                ("ntaps", C.c_int32), ("n_pre_remove", C.c_int32), ("max_blocks", C.c_int32),
+                ("taps_host", C.POINTER(C.c_float))]
+
+
+RAW_DTYPES = {"int8": 0, "uint8": 1, "int16": 2, "float32": 3, "complex64": 4}
+
 _lib = None
 _lib_lock = threading.Lock()
 
@@ -70,6 +78,14 @@ _SIGNATURES = {
     "prc_nlms_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
                                    C.c_void_p]),
+    "prc_frontend_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(FrontendDesc)]),
+    "prc_frontend_plan_destroy": (C.c_int, [C.c_void_p]),
+    "prc_frontend_out_len": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "prc_frontend_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_double,
+                                       C.POINTER(C.c_double), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "prc_deinterleave": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "prc_frequency_shift_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                            C.c_double, C.c_void_p]),
     "prc_xcorr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                             C.c_void_p]),
     "prc_frequency_shift": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,

@@ -132,6 +132,64 @@ class LsPlan:
             pass
 
 
+def resample_design(up, dn):
+    """scipy.signal.resample_poly's filter and alignment for signal_utils.resample (signal_utils.py:15-17):
+    returns (taps with n_pre_pad leading zeros, float32; n_pre_remove; up; dn) with up/dn reduced."""
+    from math import gcd
+    from scipy.signal import firwin
+    g = gcd(int(up), int(dn))
+    up, dn = int(up) // g, int(dn) // g
+    max_rate = max(up, dn)
+    half_len = 10 * max_rate
+    h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)) * up
+    n_pre_pad = dn - half_len % dn
+    taps = np.concatenate((np.zeros(n_pre_pad), h)).astype(np.float32)
+    return taps, (half_len + n_pre_pad) // dn, up, dn
+
+
+class FrontendPlan:
+    """prc_frontend_plan: deinterleave -> tune (block phase) -> resample, fused, up to max_blocks blocks."""
+
+    def __init__(self, n_in, raw_dtype, up, dn, max_blocks=1):
+        taps, npr, up, dn = resample_design(up, dn)
+        self.n_in, self.up, self.dn = int(n_in), up, dn
+        self._taps = np.ascontiguousarray(taps)
+        d = _lib.FrontendDesc()
+        d.n_in, d.raw_dtype, d.up, d.down = self.n_in, _lib.RAW_DTYPES[str(raw_dtype)], up, dn
+        d.ntaps, d.n_pre_remove, d.max_blocks = self._taps.size, npr, int(max_blocks)
+        d.taps_host = self._taps.ctypes.data_as(C.POINTER(C.c_float))
+        h = C.c_void_p()
+        check(lib().prc_frontend_plan_create(C.byref(h), C.byref(d)))
+        self._h = h
+        n = C.c_int64()
+        check(lib().prc_frontend_out_len(self._h, C.byref(n)))
+        self.n_out = n.value
+
+    def execute(self, raw, out, nblocks=1, raw_stride=None, out_stride=None, fc=0.0, fs=1.0, phases=None,
+                mix=True, stream=None):
+        ph = None
+        if phases is not None:
+            ph = (C.c_double * nblocks)(*[float(p) for p in phases])
+        itemscalars = 1 if self.raw_is_complex else 2
+        check(lib().prc_frontend_execute(self._h, _ptr(raw),
+                                         int(self.n_in * itemscalars if raw_stride is None else raw_stride),
+                                         int(bool(mix)), float(fc), float(fs), ph, _ptr(out),
+                                         int(self.n_out if out_stride is None else out_stride), int(nblocks), stream))
+
+    raw_is_complex = False
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().prc_frontend_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def nlms_execute(ref, srv, out, n, filter_len, mu, peek=10, taps_in=None, taps_out=None,
                  nstreams=1, stride=None, out_stride=None, stream=None):
     check(lib().prc_nlms_execute(_ptr(ref), _ptr(srv), int(n), int(n if stride is None else stride),

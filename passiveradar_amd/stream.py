@@ -136,6 +136,7 @@ class HipBackend:
             self.s_ls = torch.cuda.Stream(device=self.device) if self.overlap else None
             self.s_caf = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._clean_buf = None
+        self._fe_plans = {}
 
     def _stream(self):
         from . import _lib
@@ -149,6 +150,35 @@ class HipBackend:
         buf = torch.zeros(n + self.C, dtype=torch.complex64, device=self.device)
         buf[self.C // 2:self.C // 2 + n].copy_(t, non_blocking=True)
         return buf
+
+    def front_end(self, raw, input_chunk_length, offset_freq, input_sample_rate, up, dn, max_blocks=32):
+        """SURVEY 8f next #1 -- main.py:105-166 for one channel, on the device: raw interleaved scalars
+        (host array or device tensor; int8 / uint8 / int16 / float32) -> IF complex64 stream (device
+        tensor, blocks concatenated).  One fused kernel per batch of blocks."""
+        torch = self.torch
+        from . import _lib
+        t = raw if torch.is_tensor(raw) else torch.from_numpy(np.ascontiguousarray(raw))
+        if str(t.dtype).replace("torch.", "") not in _lib.RAW_DTYPES:
+            t = t.to(torch.float32)
+        t = t.to(self.device, non_blocking=True).contiguous()
+        icl = int(input_chunk_length)
+        nblocks = int(t.shape[0]) // icl
+        n_in = icl // 2
+        key = (n_in, str(t.dtype), int(up), int(dn), int(max_blocks))
+        plan = self._fe_plans.get(key)
+        if plan is None:
+            with torch.cuda.device(self.device):
+                plan = self._fe_plans[key] = self.engine.FrontendPlan(n_in, str(t.dtype).replace("torch.", ""),
+                                                                      up, dn, max_blocks)
+        per_block = n_in % (input_sample_rate // offset_freq)                       # main.py:125-130
+        phases = 2 * np.pi * np.arange(nblocks) * per_block * (offset_freq / input_sample_rate)
+        out = torch.empty(nblocks * plan.n_out, dtype=torch.complex64, device=self.device)
+        with torch.cuda.device(self.device):
+            for b0 in range(0, nblocks, max_blocks):
+                nb = min(max_blocks, nblocks - b0)
+                plan.execute(t[b0 * icl:], out[b0 * plan.n_out:], nb, icl, plan.n_out, offset_freq,
+                             input_sample_rate, phases[b0:b0 + nb], True, self._stream())
+        return out
 
     def _clean_target(self, srv_pad):
         # the cleaned stream buffer is reused across calls; only its two C/2 pads must be zero and
@@ -266,6 +296,15 @@ class StreamProcessor:
         if self.world == 1 or not gather:
             return frames
         return gather_frames(frames, sh, self.group)
+
+    def process_raw(self, raw_ref, raw_srv, config, gather=True):
+        """main.py:105-194 from the raw interleaved recordings: front end per channel (device), then
+        the LS + CAF pipeline.  ``config`` is the dict of passiveradar_amd.config.getConfiguration."""
+        args = (config["input_chunk_length"], config["offset_freq"], config["input_sample_rate"],
+                config["resamp_up"], config["resamp_dn"])
+        ref = self.backend.front_end(raw_ref, *args)
+        srv = self.backend.front_end(raw_srv, *args)
+        return self.process(ref, srv, gather=gather)
 
     @staticmethod
     def to_reference_layout(frames):

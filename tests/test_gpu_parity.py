@@ -247,3 +247,22 @@ def test_concurrent_callers():
     assert not errs, errs
     for (gx, gl), (ex, el) in zip(got, exp):
         assert rel_err(gx, ex) < TIGHT and rel_err(gl, el) < TIGHT
+
+
+def test_front_end_golden():
+    """SURVEY 8f next #1 on the GPU: fused deinterleave -> block-phase tuning -> 13:119 resampler."""
+    from passiveradar_amd.signal_utils import deinterleave_IQ, frequency_shift, front_end, resample
+    g = load_golden("frontend")
+    icl, fs, foff, up, dn = int(g["icl"]), int(g["fs"]), int(g["foff"]), int(g["up"]), int(g["dn"])
+    assert np.array_equal(deinterleave_IQ(g["rawf"]), g["deintf"])
+    assert np.array_equal(deinterleave_IQ(g["raw8"][icl:2 * icl]), g["deint1"])
+    tuned = frequency_shift(g["deint1"], foff, fs, np.array([g["phases"][1]]))
+    assert tuned.dtype == np.complex128 and rel_err(tuned, g["tuned1"]) < 1e-6
+    out = front_end(g["raw8"], icl, foff, fs, up, dn)
+    assert out.dtype == np.complex64 and out.shape == g["out"].shape
+    assert rel_err(out, g["out"]) < TIGHT
+    out2 = front_end(g["raw8"], icl, foff, fs, up, dn, max_blocks=2)       # batches of 2 + 1 blocks
+    assert np.array_equal(out, out2)
+    assert rel_err(resample(g["deint1"], 3, 7), g["res_c64"]) < TIGHT
+    r = resample(g["tuned1"], up, dn)
+    assert r.dtype == np.complex128 and rel_err(r, g["out"][len(g["out"]) // 3:2 * len(g["out"]) // 3]) < TIGHT

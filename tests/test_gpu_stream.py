@@ -66,3 +66,37 @@ def test_cfg2_pipeline_properties():
     ridge = mid[F // 2, [R - 2, R - 9, R - 40]]
     tgt = mid[scene.expected_peak_cell(60, 80.0, n, fs, R, F)]
     assert ridge.max() < 0.1 * tgt
+
+
+def test_raw_to_frames_small_config():
+    """front end + LS + CAF from raw int8 recordings against the oracle's restatement of main.py:105-194"""
+    import torch
+    from oracle import np_oracle as O
+    from passiveradar_amd.stream import HipBackend, StreamProcessor
+    rng = np.random.default_rng(12)
+    cfg = dict(input_chunk_length=2 * 37490, offset_freq=100000, input_sample_rate=2400000,
+               resamp_up=13, resamp_dn=119, cpi_samples=8192, num_range_cells=16, num_doppler_cells=32,
+               IF_sample_rate=2400000 * 13 / 119)
+    nblk = 4
+    n_raw = cfg["input_chunk_length"] * nblk
+    base = rng.standard_normal(n_raw // 2 + 64) + 1j * rng.standard_normal(n_raw // 2 + 64)
+    refc = base[64:]
+    srvc = 0.9 * base[62:-2] + 0.2 * base[40:-24] + 0.05 * (rng.standard_normal(n_raw // 2) + 0j)
+    def to_raw(z):
+        r = np.empty(n_raw, np.int8)
+        r[0::2] = np.clip(np.round(z.real * 25), -127, 127)
+        r[1::2] = np.clip(np.round(z.imag * 25), -127, 127)
+        return r
+    raw_ref, raw_srv = to_raw(refc), to_raw(srvc)
+    # ceil(37490 complex samples * 13/119) = 4096 IF samples per block = cpi/2
+    fe = lambda r: O.front_end(r, cfg["input_chunk_length"], cfg["offset_freq"], cfg["input_sample_rate"], 13, 119)
+    ref_if, srv_if = fe(raw_ref), fe(raw_srv)
+    assert ref_if.shape[0] == nblk * 4096
+    exp = O.process_stream(ref_if.astype(np.complex64), srv_if.astype(np.complex64), cfg["cpi_samples"], 16, 32,
+                           cfg["IF_sample_rate"])
+    sp = StreamProcessor(HipBackend(cfg["cpi_samples"], 16, 32, cfg["IF_sample_rate"], batch=4))
+    got = sp.process_raw(raw_ref, raw_srv, cfg)
+    torch.cuda.synchronize()
+    got = StreamProcessor.to_reference_layout(got).cpu().numpy()
+    assert got.shape == exp.shape
+    assert rel_err(got, exp) < 1e-4

@@ -147,3 +147,18 @@ def test_ls_libcalls_form_matches():
     g = load_golden("ls_multiple")
     out = O.LS_Filter_Multiple_libcalls(g["ref"], g["srv"], int(g["L"]), float(g["fs"]), list(g["bins"]))
     assert rel_err(out, g["out"]) < 1e-7
+
+
+def test_front_end_restatement():
+    """SURVEY 8f next #1: deinterleave / block-phase tuning / polyphase 'line' resampler."""
+    g = load_golden("frontend")
+    assert np.array_equal(O.deinterleave_IQ(g["rawf"]), g["deintf"])
+    icl = int(g["icl"])
+    assert np.array_equal(O.deinterleave_IQ(g["raw8"][icl:2 * icl]), g["deint1"])
+    tuned = O.frequency_shift(g["deint1"], int(g["foff"]), int(g["fs"]), np.array([g["phases"][1]]))
+    assert tuned.dtype == np.complex128 and rel_err(tuned, g["tuned1"]) < 1e-12
+    out = O.front_end(g["raw8"], icl, int(g["foff"]), int(g["fs"]), int(g["up"]), int(g["dn"]))
+    assert out.dtype == np.complex128 and out.shape == g["out"].shape
+    assert rel_err(out, g["out"]) < 1e-12
+    assert rel_err(O.resample(g["deint1"], 3, 7), g["res_c64"]) < 2e-6
+    assert rel_err(O.resample(g["deint1"][:5000], 13, 119), g["res_simple"]) < 2e-6
