@@ -193,6 +193,13 @@ int prc_deinterleave(const void* raw, int32_t raw_dtype, int64_t n_complex, void
 int prc_frequency_shift_block(const void* x, void* y, int64_t n, double fc, double fs,
                               double block_phase, void* stream);
 
+/* ---- CFAR_2D (SURVEY 8f "next" #3): target_detection.py:683-703 ------------------------------ */
+/* X: float32 [nframes][H][W] (|xambg|, H = Doppler rows, W = range columns); out float32 same shape:
+ * the CFAR ratio, or 0/1 where ratio > thresh when use_thresh != 0.  Wrap-around box filter of width fw
+ * with the (gw+1)^2 guard hole and the 1/(fw^2-gw^2) gain of the reference, normalised by mean|X|. */
+int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int32_t gw, int32_t use_thresh,
+               float thresh, float* out, int32_t nframes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

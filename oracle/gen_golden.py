@@ -224,6 +224,21 @@ def frontend_case():
          res_c64=ref_su.resample(deint1, 3, 7), res_simple=ref_su.resample(deint1[:5000], 13, 119))
 
 
+def cfar_case():
+    """SURVEY 8f next #3: CFAR_2D (target_detection.py:683-703) on a |fast_xambg| map."""
+    print("CFAR_2D")
+    np.float = float          # target_detection.py:10-17 uses aliases removed in NumPy >= 1.24
+    np.int = int
+    from passiveRadar import target_detection as ref_td
+    n, R, F = 16384, 40, 64
+    a, s = scene.make_scene(n, 1e4, R, scene.scene_seed(89), targets=((13, 37.0, 0.2), (30, -11.0, 0.1)))
+    X = np.abs(ref_rd.fast_xambg(a, s, R, F))[:, :, 0]
+    cr = ref_td.CFAR_2D(X, 18, 4)
+    thr = float(np.sort(cr.ravel())[-12])          # a threshold that keeps a dozen cells
+    save("cfar", X=X, cr_18_4=cr, cr_7_2=ref_td.CFAR_2D(X, 7, 2), thr=thr,
+         det_18_4=ref_td.CFAR_2D(X, 18, 4, thr))
+
+
 def big_cases():
     print("big CAF cases (root finder short-circuited)")
     with no_root_finding():
@@ -274,5 +289,6 @@ if __name__ == "__main__":
         config_cases()
         stream_case()
         frontend_case()
+        cfar_case()
     if args.big or args.only_big:
         big_cases()

@@ -466,3 +466,27 @@ def front_end(raw, input_chunk_length, offset_freq, input_sample_rate, up, dn):
         tuned = frequency_shift(blk, offset_freq, input_sample_rate, np.array([ph[i]]))
         out.append(resample(tuned, up, dn))
     return np.concatenate(out)
+
+
+# --------------------------------------------------------------------------
+# CFAR (SURVEY 8f "next" #3): target_detection.py:683-703
+# --------------------------------------------------------------------------
+
+def CFAR_2D(X, fw, gw, thresh=None):
+    """target_detection.py:683-703 with scipy.signal.convolve2d(mode='same', boundary='wrap') spelled
+    out:  box[i,j] = sum_{a,b} T[a,b] X[(i + (fw-1)//2 - a) mod H, (j + (fw-1)//2 - b) mod W],
+    T = 1/(fw^2-gw^2) outside the guard block [e1,e2)^2, e1 = (fw-gw)//2, e2 = fw-e1+1."""
+    X = np.asarray(X)
+    e1 = (fw - gw) // 2
+    e2 = fw - e1 + 1
+    c = (fw - 1) // 2
+    box = np.zeros(X.shape, dtype=np.float64)
+    Xd = X.astype(np.float64)
+    for a in range(fw):
+        for b in range(fw):
+            if e1 <= a < e2 and e1 <= b < e2:
+                continue
+            box += np.roll(np.roll(Xd, a - c, axis=0), b - c, axis=1)     # X[i + c - a, j + c - b]
+    box /= (fw ** 2 - gw ** 2)
+    cr = (X / np.mean(np.abs(X).flatten())) / (box + 1e-10)
+    return cr if thresh is None else cr > thresh

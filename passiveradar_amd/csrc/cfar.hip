@@ -1,0 +1,92 @@
+// CFAR_2D on device (SURVEY 8f "next" #3): target_detection.py:683-703 as called per frame at
+// range_doppler_plot.py:56-57 on |xambg|.
+//   Tfilt = ones(fw,fw)/(fw^2-gw^2), Tfilt[e1:e2, e1:e2] = 0, e1 = (fw-gw)//2, e2 = fw-e1+1
+//   CR = (X / mean|X|) / (convolve2d(X, Tfilt, 'same', boundary='wrap') + 1e-10)
+// 'same' centring of scipy.signal.convolve2d: out[i,j] = sum_{a,b} T[a,b] X[(i + (fw-1)/2 - a) mod H,
+// (j + (fw-1)/2 - b) mod W]  (asymmetric for even fw -- reproduced, not "fixed").
+// One pass for the mean (block partials), one pass for the box sums from an LDS tile with wrap halo.
+#include "common.h"
+
+#define CF_TX 32
+#define CF_TY 8
+
+__global__ void cfar_abs_partial_kernel(const float* __restrict__ X, int64_t n, float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int f = blockIdx.y;
+    const float* x = X + (int64_t)f * n;
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += fabsf(x[i]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(int64_t)f * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(CF_TX * CF_TY) void cfar_kernel(const float* __restrict__ X, int H, int W, int fw,
+                                                             int e1, int e2, float inv_cells,
+                                                             const float* __restrict__ partial, int npartial,
+                                                             float thresh, int use_thresh, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* tile = reinterpret_cast<float*>(smem_raw);        // (CF_TY + fw - 1) x (CF_TX + fw - 1)
+    const int f = blockIdx.z;
+    const float* x = X + (int64_t)f * H * W;
+    const int c = (fw - 1) / 2;
+    const int th = CF_TY + fw - 1, tw = CF_TX + fw - 1;
+    const int i0 = blockIdx.y * CF_TY, j0 = blockIdx.x * CF_TX;
+    // tile element (r, s) <-> X[(i0 + c - (fw-1) + r) mod H, (j0 + c - (fw-1) + s) mod W]
+    const int ib = i0 + c - (fw - 1), jb = j0 + c - (fw - 1);
+    for (int t = threadIdx.x; t < th * tw; t += CF_TX * CF_TY) {
+        const int r = t / tw, s = t - r * tw;
+        int ii = (ib + r) % H, jj = (jb + s) % W;
+        if (ii < 0) ii += H;
+        if (jj < 0) jj += W;
+        tile[t] = x[(int64_t)ii * W + jj];
+    }
+    float tot = 0.f;
+    for (int k = 0; k < npartial; ++k) tot += partial[(int64_t)f * npartial + k];
+    const float mean_abs = tot / (float)((int64_t)H * W);
+    __syncthreads();
+    const int ty = threadIdx.x / CF_TX, tx = threadIdx.x % CF_TX;
+    const int i = i0 + ty, j = j0 + tx;
+    if (i >= H || j >= W) return;
+    // X index for tap (a, b): row i + c - a  -> tile row (fw-1) + ty - a
+    float acc = 0.f;
+    for (int a = 0; a < fw; ++a) {
+        const float* row = tile + ((fw - 1) + ty - a) * tw + (fw - 1) + tx;
+        const bool guard_row = a >= e1 && a < e2;
+        for (int b = 0; b < fw; ++b) {
+            if (guard_row && b >= e1 && b < e2) continue;
+            acc += row[-b];
+        }
+    }
+    const float xv = tile[((fw - 1) + ty - c) * tw + (fw - 1) + tx - c];
+    const float cr = (xv / mean_abs) / (acc * inv_cells + 1e-10f);
+    out[(int64_t)f * H * W + (int64_t)i * W + j] = use_thresh ? (cr > thresh ? 1.f : 0.f) : cr;
+}
+
+extern "C" int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int32_t gw, int32_t use_thresh,
+                          float thresh, float* out, int32_t nframes, void* stream_) {
+    PRC_REQUIRE(X && out, PRC_EINVAL, "prc_cfar2d: null argument");
+    PRC_REQUIRE(H > 0 && W > 0 && fw > 0 && gw >= 0 && nframes > 0, PRC_EINVAL, "prc_cfar2d: bad size");
+    PRC_REQUIRE(fw * fw != gw * gw, PRC_EINVAL, "prc_cfar2d: fw^2 == gw^2 divides by zero (as in the reference)");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int np = 64;
+    float* d_partial = nullptr;
+    PRC_HIP(hipMallocAsync((void**)&d_partial, sizeof(float) * np * nframes, stream));
+    hipLaunchKernelGGL(cfar_abs_partial_kernel, dim3(np, nframes), dim3(256), 0, stream, X, (int64_t)H * W, d_partial);
+    int e1 = (fw - gw) / 2, e2 = fw - e1 + 1;
+    if (e1 < 0) e1 = 0;
+    if (e2 > fw) e2 = fw;
+    const size_t lds = sizeof(float) * (size_t)(CF_TY + fw - 1) * (CF_TX + fw - 1);
+    PRC_REQUIRE(lds <= 64 * 1024, PRC_EUNSUPPORTED, "prc_cfar2d: kernel width %d too large", fw);
+    dim3 grid((W + CF_TX - 1) / CF_TX, (H + CF_TY - 1) / CF_TY, nframes);
+    hipLaunchKernelGGL(cfar_kernel, grid, dim3(CF_TX * CF_TY), lds, stream, X, H, W, fw, e1, e2,
+                       1.0f / (float)(fw * fw - gw * gw), d_partial, np, thresh, use_thresh, out);
+    hipError_t le = hipGetLastError();
+    (void)hipFreeAsync(d_partial, stream);
+    if (le != hipSuccess) { prc_set_error("prc_cfar2d: launch failed: %s", hipGetErrorString(le)); return PRC_EHIP; }
+    return PRC_OK;
+}

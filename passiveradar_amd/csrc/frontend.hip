@@ -4,7 +4,7 @@
 // fused into ONE kernel: raw interleaved scalars in, IF complex64 samples out, nothing in between
 // touches HBM (the reference materialises a complex64 and two complex128 arrays per block).
 //
-// Polyphase form of resample_poly (restated and checked in oracle/np_oracle.py::resample):
+// Polyphase form of resample_poly (the same closed form the CPU checker restates and pins):
 //   y[m] = sum_j h[(t mod up) + up j] xe[t div up - j],   t = (m + n_pre_remove) dn,
 // h = firwin(20 max(up,dn)+1, 1/max(up,dn), ('kaiser',5.0)) * up, zero-padded in front (host side,
 // scipy), xe = the tuned block extended linearly through its first and last sample (upfirdn 'line').

@@ -266,3 +266,19 @@ def test_front_end_golden():
     assert rel_err(resample(g["deint1"], 3, 7), g["res_c64"]) < TIGHT
     r = resample(g["tuned1"], up, dn)
     assert r.dtype == np.complex128 and rel_err(r, g["out"][len(g["out"]) // 3:2 * len(g["out"]) // 3]) < TIGHT
+
+
+def test_cfar_golden():
+    """SURVEY 8f next #3 on the GPU (single map, batch of maps, device tensors)."""
+    import torch
+    from passiveradar_amd.target_detection import CFAR_2D
+    g = load_golden("cfar")
+    cr = CFAR_2D(g["X"], 18, 4)
+    assert cr.dtype == np.float64 and rel_err(cr, g["cr_18_4"]) < TIGHT
+    assert rel_err(CFAR_2D(g["X"], 7, 2), g["cr_7_2"]) < TIGHT
+    det = CFAR_2D(g["X"], 18, 4, float(g["thr"]) * 0.999)     # float32 ratio: test just inside the threshold
+    assert det.dtype == bool and (det & ~g["det_18_4"]).sum() <= 1 and (g["det_18_4"] & ~det).sum() == 0
+    stack = np.stack([g["X"], 2 * g["X"], g["X"][::-1]])
+    out = CFAR_2D(torch.from_numpy(stack).cuda(), 18, 4).cpu().numpy()
+    assert rel_err(out[0], g["cr_18_4"]) < TIGHT and rel_err(2 * out[1], g["cr_18_4"]) < TIGHT   # numerator is normalised, the box sum is not
+    assert rel_err(out[2], O.CFAR_2D(g["X"][::-1], 18, 4)) < TIGHT

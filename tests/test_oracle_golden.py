@@ -162,3 +162,12 @@ def test_front_end_restatement():
     assert rel_err(out, g["out"]) < 1e-12
     assert rel_err(O.resample(g["deint1"], 3, 7), g["res_c64"]) < 2e-6
     assert rel_err(O.resample(g["deint1"][:5000], 13, 119), g["res_simple"]) < 2e-6
+
+
+def test_cfar_restatement():
+    """SURVEY 8f next #3: wrap-around box filter with the reference's asymmetric guard block."""
+    g = load_golden("cfar")
+    assert rel_err(O.CFAR_2D(g["X"], 18, 4), g["cr_18_4"]) < 1e-12
+    assert rel_err(O.CFAR_2D(g["X"], 7, 2), g["cr_7_2"]) < 1e-12
+    det = O.CFAR_2D(g["X"], 18, 4, float(g["thr"]))
+    assert det.dtype == bool and np.array_equal(det, g["det_18_4"]) and 5 < det.sum() < 30
