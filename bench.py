@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--caf-method", type=int, default=0, help="0 auto, 1 direct, 2 fft")
     ap.add_argument("--doppler", type=int, default=0, help="0 auto, 1 rocfft, 2 fused")
     ap.add_argument("--ls-method", type=int, default=0, help="0 auto, 1 time-domain, 2 FFT, 3 FFT + spectrum cache")
+    ap.add_argument("--nsub", type=int, default=2, help="LS sub-batches per step when stages are pipelined")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run LS and CAF back to back on one stream instead of pipelining sub-batches on two")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -138,7 +139,7 @@ def main():
     B = args.frames
     C = n // 2
     be = prstream.HipBackend(n, R, F, fs, clutter=clutter, batch=B, device=device,
-                             caf_method=args.caf_method, doppler_method=args.doppler, overlap=not args.no_overlap, ls_method=args.ls_method)
+                             caf_method=args.caf_method, doppler_method=args.doppler, overlap=not args.no_overlap, ls_method=args.ls_method, nsub=args.nsub)
     ref, srv = synth_stream(torch, B, C, fs, R, 20260926 + rank, device)
     ref_pad = be.padded(ref)
     srv_pad = be.padded(srv)

@@ -25,7 +25,6 @@ struct prc_caf_plan {
     float2* d_y2 = nullptr;          // [j][k]-ordered staging written by the FFT segment kernel
     size_t y_bytes = 0;
     rocfft_plan fft = nullptr;       // one batched plan for max_frames
-    int fft_frames = 0;
     rocfft_execution_info info = nullptr;
     void* d_work = nullptr;
     size_t work_bytes = 0;
@@ -75,7 +74,6 @@ static int build_rocfft(prc_caf_plan* p, int frames) {
         st = rocfft_execution_info_set_work_buffer(p->info, p->d_work, p->work_bytes);
         PRC_REQUIRE(st == rocfft_status_success, PRC_EROCFFT, "rocfft set work buffer failed (%d)", (int)st);
     }
-    p->fft_frames = frames;
     return PRC_OK;
 }
 

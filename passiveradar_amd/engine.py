@@ -153,6 +153,7 @@ class FrontendPlan:
     def __init__(self, n_in, raw_dtype, up, dn, max_blocks=1):
         taps, npr, up, dn = resample_design(up, dn)
         self.n_in, self.up, self.dn = int(n_in), up, dn
+        self.raw_is_complex = str(raw_dtype) == "complex64"     # raw_stride then counts complex samples
         self._taps = np.ascontiguousarray(taps)
         d = _lib.FrontendDesc()
         d.n_in, d.raw_dtype, d.up, d.down = self.n_in, _lib.RAW_DTYPES[str(raw_dtype)], up, dn
@@ -175,8 +176,6 @@ class FrontendPlan:
                                          int(self.n_in * itemscalars if raw_stride is None else raw_stride),
                                          int(bool(mix)), float(fc), float(fs), ph, _ptr(out),
                                          int(self.n_out if out_stride is None else out_stride), int(nblocks), stream))
-
-    raw_is_complex = False
 
     def close(self):
         if getattr(self, "_h", None):

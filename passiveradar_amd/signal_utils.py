@@ -76,7 +76,6 @@ def resample(x, up, dn):
     n = xc.shape[0]
     plan = engine.cached_plan(("fe", n, "complex64", int(up), int(dn)),
                               lambda: engine.FrontendPlan(n, "complex64", up, dn, 1))
-    plan.raw_is_complex = True
     st = engine.staging()
     dx = st.get("rs_x", 8 * n)
     do = st.get("rs_o", 8 * plan.n_out)

@@ -107,7 +107,7 @@ class HipBackend:
     def __init__(self, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
                  doppler_bins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), clutter="ls",
                  batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, overlap=True,
-                 ls_method=0):
+                 ls_method=0, nsub=2):
         import torch
         from . import engine
         from .range_doppler_processing import _named_window
@@ -124,7 +124,7 @@ class HipBackend:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         # pipelining doubles the latency-bound solve launches; it only pays once they are amortised
         self.overlap = bool(overlap) and clutter == "ls" and self.batch >= 128
-        self.sub = -(-self.batch // 2) if self.overlap else self.batch     # chunks per LS launch
+        self.sub = -(-self.batch // max(int(nsub), 1)) if self.overlap else self.batch   # chunks per LS launch
         with torch.cuda.device(self.device):
             self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch, caf_method, doppler_method)
             self.ls = engine.LsPlan(self.C, self.R, 10, False, self.sub, ls_method) if clutter == "ls" else None
