@@ -78,3 +78,28 @@ def expected_peak_cell(delay, doppler_hz, n, sample_rate, rangeBins, freqBins):
     cpi = n / float(sample_rate)
     row = int(round(freqBins / 2 - doppler_hz * cpi)) % freqBins
     return row, rangeBins - delay
+
+
+def make_fm_scene(n, sample_rate, rangeBins, seed, deviation=75e3, audio_bw=15e3, **kw):
+    """Report-only scene of SURVEY 8d: the reference channel is an FM broadcast-like signal (band-limited
+    Gaussian audio, ``deviation`` Hz peak-ish deviation, unit amplitude) instead of white noise.  Its
+    autocorrelation matrix is badly conditioned (1e6..1e7), so element-wise parity against the
+    float32-summing reference is not meaningful -- clutter suppression in dB is."""
+    gen = np.random.Generator(np.random.Philox(key=seed))
+    spec = np.fft.rfft(gen.standard_normal(n))
+    f = np.fft.rfftfreq(n, 1.0 / sample_rate)
+    spec[f > audio_bw] = 0.0
+    audio = np.fft.irfft(spec, n)
+    audio /= 3.0 * np.std(audio)                      # +-1 at three sigma
+    phase = 2 * np.pi * deviation * np.cumsum(audio) / sample_rate
+    ref = np.exp(1j * phase).astype(np.complex64)
+    noise = _cwhite(gen, n)
+    targets = kw.get("targets", default_targets(rangeBins))
+    acc = np.zeros(n, dtype=np.complex128)
+    for d, a in kw.get("clutter", DEFAULT_CLUTTER):
+        acc += a * np.roll(ref, d)
+    t = np.arange(n, dtype=np.float64) / float(sample_rate)
+    for d, fd, a in targets:
+        acc += a * np.roll(ref, d) * np.exp(2j * np.pi * fd * t)
+    acc += kw.get("noise_amp", 0.003) * noise
+    return ref, acc.astype(np.complex64)
