@@ -101,3 +101,20 @@ def test_shape_errors_are_raised_before_any_device_call():
                lambda: LS_Filter_Multiple(a, b, 4, 1e3), lambda: LS_Filter(a, b, 4)):
         with pytest.raises(ValueError):
             fn()
+
+
+def test_output_store_roundtrip(tmp_path):
+    """main.py:200-224 geometry: (F, R+1, nframes) complex64, one uncompressed zarr-v2 chunk per frame"""
+    from passiveradar_amd import output
+    rng = np.random.default_rng(3)
+    frames = (rng.standard_normal((5, 8, 4)) + 1j * rng.standard_normal((5, 8, 4))).astype(np.complex64)
+    p = output.save_range_doppler_zarr(str(tmp_path / "XAMBG.zarr"), frames)
+    meta = json.load(open(os.path.join(p, ".zarray")))
+    assert meta["shape"] == [8, 4, 5] and meta["chunks"] == [8, 4, 1] and meta["order"] == "C"
+    assert os.path.getsize(os.path.join(p, "0.0.3")) == 8 * 4 * 8
+    back = output.load_range_doppler_zarr(p)
+    assert np.array_equal(back, np.moveaxis(frames, 0, 2))
+    cfg = dict(num_doppler_cells=8, num_range_cells=3, frame_interval=0.5, range_cell_width=1.1,
+               doppler_cell_width=0.5, meta_fname=str(tmp_path / "m.npz"))
+    m = np.load(output.save_metadata(cfg, 5))
+    assert m["frame_timestamps"].shape == (5,) and m["range_bins"].shape == (4,) and m["doppler_bins"].shape == (16,)
