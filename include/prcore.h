@@ -200,6 +200,31 @@ int prc_frequency_shift_block(const void* x, void* y, int64_t n, double fc, doub
 int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int32_t gw, int32_t use_thresh,
                float thresh, float* out, int32_t nframes, void* stream);
 
+/* ---- channel offset estimation (SURVEY 8f "next" #2): signal_utils.py:73-78 ------------------- */
+/* The zero-phase IIR decimator of scipy.signal.decimate(x, q) (ftype 'iir', zero_phase=True:
+ * sosfiltfilt of a Chebyshev-I low-pass, odd extension of `padlen` samples each side, steady-state
+ * initial conditions) as two spectral passes H then conj(H) on device.  The host designs the filter
+ * (zeros/poles/gain of the digital low-pass) and says how many samples its impulse response needs to
+ * settle (`settle`, >= log(1e-9)/log(max|pole|)). */
+typedef struct prc_iir_desc {
+    int32_t q;             /* keep every q-th filtered sample                                    */
+    int32_t padlen;        /* sosfiltfilt's odd-extension length, 3*(2*nsections+1 - ...) = 27    */
+    int32_t settle;        /* constant-extension length standing in for the steady-state zi      */
+    int32_t nzeros, npoles;/* <= 16 each                                                          */
+    const double* zeros_host;  /* HOST (re, im) pairs                                             */
+    const double* poles_host;  /* HOST (re, im) pairs                                             */
+    double gain;
+} prc_iir_desc;
+/* y[j] = filtfilt(x)[j*q], j < ceil(n/q); x, y complex64 DEVICE.  PRC_ESHAPE if n <= padlen. */
+int prc_decimate_iir(const void* x, int64_t n, const prc_iir_desc* iir, void* y, void* stream);
+/* find_channel_offset(s1, s2, nd, nl), signal_utils.py:73-78: B1 = decimate(s1, nd), B2 = decimate(s2, nd)
+ * zero-padded by nl each side, xc = |correlate(B1, B2, 'valid')| (m2 + 2 nl - m1 + 1 values,
+ * xc[i] = |sum_l B1[l] conj(B2[l + m2 - m1 + nl - i])|), via rocFFT.  xc_out: DEVICE float32[n_xc] or
+ * NULL; *argmax_out (HOST) = first index of the maximum, so the reference's return value is
+ * (*argmax_out - nl) * nd.  Synchronises `stream` before returning. */
+int prc_channel_offset(const void* s1, int64_t n1, const void* s2, int64_t n2, const prc_iir_desc* iir,
+                       int64_t nl, float* xc_out, int64_t* n_xc, int64_t* argmax_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,8 @@
  *   orc_nlms          clutter_removal.py:189-249  (NLMS_filter; complex64 state, sequential)
  *   orc_caf_segments  range_doppler_processing.py:81-86 with the boxcar decimator (:72):
  *                     y[j,k] = sum_{n=jq-ceil(q/2)}^{jq+floor(q/2)} w[n] ref[n] conj(srv[(n+R-k) mod N])
+ *   orc_sosfilt       the serial recursion under signal.decimate(x, q) in find_channel_offset
+ *                     (signal_utils.py:73-78), complex128
  */
 #include <complex.h>
 #include <stdint.h>
@@ -70,6 +72,24 @@ int orc_caf_segments(const c64* ref, const c64* srv, int64_t n, int R, int F, co
             }
             y[(int64_t)j * (R + 1) + k] = acc;
         }
+    }
+    return 0;
+}
+
+/* One direction of scipy.signal.sosfilt (transposed direct form II, _sosfilt.pyx) as sosfiltfilt runs it
+ * inside signal.decimate(x, q) -- signal_utils.py:75-76.  sos: nsec x 6 (b0 b1 b2 1 a1 a2), x filtered
+ * in place, zi: nsec x 2 state carried in and out. */
+int orc_sosfilt(const double* sos, int nsec, c128* x, int64_t n, c128* zi) {
+    for (int64_t i = 0; i < n; ++i) {
+        c128 cur = x[i];
+        for (int s = 0; s < nsec; ++s) {
+            const double* c = sos + 6 * s;
+            c128 nw = c[0] * cur + zi[2 * s];
+            zi[2 * s] = c[1] * cur - c[4] * nw + zi[2 * s + 1];
+            zi[2 * s + 1] = c[2] * cur - c[5] * nw;
+            cur = nw;
+        }
+        x[i] = cur;
     }
     return 0;
 }

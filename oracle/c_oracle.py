@@ -26,7 +26,20 @@ def lib():
         _lib.orc_caf_segments.restype = C.c_int
         _lib.orc_caf_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p]
+        _lib.orc_sosfilt.restype = C.c_int
+        _lib.orc_sosfilt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     return _lib
+
+
+def sosfilt(sos, x, zi):
+    """scipy.signal.sosfilt(sos, x, zi=zi) -> (y, zf), complex128, one-dimensional."""
+    sos = np.ascontiguousarray(sos, dtype=np.float64)
+    y = np.array(x, dtype=np.complex128, order="C")
+    z = np.array(zi, dtype=np.complex128, order="C")
+    assert sos.shape[1] == 6 and z.shape == (sos.shape[0], 2)
+    rc = lib().orc_sosfilt(sos.ctypes.data, sos.shape[0], y.ctypes.data, y.shape[0], z.ctypes.data)
+    assert rc == 0
+    return y, z
 
 
 def nlms(ref, srv, L, mu, peek=10, initialTaps=None):

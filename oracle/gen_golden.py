@@ -239,6 +239,33 @@ def cfar_case():
          det_18_4=ref_td.CFAR_2D(X, 18, 4, thr))
 
 
+def offset_case():
+    """find_channel_offset (signal_utils.py:73-78) as main.py:54/:83 calls it (nd=1) and
+    as signal_preview.py:36 does (nd=4); plus the intermediate signal.decimate output it is built on."""
+    print("find_channel_offset")
+    rng = np.random.Generator(np.random.Philox(key=scene.scene_seed(77)))
+
+    def cw(n):
+        return (rng.standard_normal(2 * n, dtype=np.float32) * np.float32(np.sqrt(0.5))).view(np.complex64)
+
+    out = {}
+    cases = (("a", 20000, 20000, 1, 1500, 137), ("b", 30001, 30001, 4, 500, -91), ("c", 16000, 13000, 2, 2000, 420),
+             ("d", 4096, 4096, 1, 64, 0), ("e", 9000, 9000, 1, 100, -100))
+    for tag, n1, n2, nd, nl, shift in cases:
+        base = cw(max(n1, n2) + 1000)
+        s1 = base[500:500 + n1].copy()
+        s2 = (0.7 * base[500 - shift:500 - shift + n2] + 0.5 * cw(n2)).astype(np.complex64)   # s2[n] = s1[n - shift]
+        B1 = signal.decimate(s1, nd)
+        B2 = np.pad(signal.decimate(s2, nd), (nl, nl), "constant")
+        xc = np.abs(signal.correlate(B1, B2, mode="valid"))
+        off = ref_su.find_channel_offset(s1, s2, nd, nl)
+        assert off == (np.argmax(xc) - nl) * nd
+        print(f"  case {tag}: n=({n1},{n2}) nd={nd} nl={nl} true shift {shift} -> offset {off}")
+        out.update({f"{tag}_s1": s1, f"{tag}_s2": s2, f"{tag}_nd": nd, f"{tag}_nl": nl, f"{tag}_offset": int(off),
+                    f"{tag}_xc": xc.astype(np.float32), f"{tag}_B1_head": B1[:1500].astype(np.complex64), f"{tag}_B1_tail": B1[-1500:].astype(np.complex64)})
+    save("channel_offset", cases=np.array([c[0] for c in cases]), **out)
+
+
 def big_cases():
     print("big CAF cases (root finder short-circuited)")
     with no_root_finding():
@@ -278,8 +305,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also generate the cfg1/2/3 CAF goldens (minutes)")
     ap.add_argument("--only-big", action="store_true")
+    ap.add_argument("--only", default=None, help="run a single case function by name, e.g. offset_case")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
+    if args.only:
+        globals()[args.only]()
+        sys.exit(0)
     if not args.only_big:
         artefact_check()
         caf_cases()
@@ -290,5 +321,6 @@ if __name__ == "__main__":
         stream_case()
         frontend_case()
         cfar_case()
+        offset_case()
     if args.big or args.only_big:
         big_cases()

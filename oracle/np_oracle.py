@@ -34,6 +34,7 @@ __all__ = [
     "decimation_taps", "caf_segment_sums", "fast_xambg", "fast_xambg_libcalls",
     "direct_xambg", "xcorr", "frequency_shift", "levinson_hermitian",
     "LS_Filter_Toeplitz", "LS_Filter_Multiple", "LS_Filter", "NLMS_filter",
+    "decimate_iir", "find_channel_offset", "CFAR_2D", "front_end", "resample", "deinterleave_IQ",
     "overlap_frames", "process_stream",
 ]
 
@@ -490,3 +491,124 @@ def CFAR_2D(X, fw, gw, thresh=None):
     box /= (fw ** 2 - gw ** 2)
     cr = (X / np.mean(np.abs(X).flatten())) / (box + 1e-10)
     return cr if thresh is None else cr > thresh
+
+
+# --------------------------------------------------------------------------
+# Channel offset estimation (SURVEY 8f "next" #2): signal_utils.py:73-78
+# --------------------------------------------------------------------------
+# scipy.signal.decimate(x, q) with its defaults (SciPy 1.15.3 _signaltools.py: ftype='iir', n=8,
+# zero_phase=True) is  sosfiltfilt(cheby1(8, 0.05, 0.8/q, output='sos'), x)[::q].  Restated below from the
+# published algorithms: Chebyshev-I analog prototype + bilinear transform, sosfilt_zi's steady state,
+# sosfiltfilt's odd extension of 3*(2*n_sections+1) samples, transposed-direct-form-II recursion
+# (oracle/c/oracle.c:orc_sosfilt, or the Python loop for small inputs).
+
+def cheby1_lowpass_sos(order, rp, wn):
+    """Second-order sections [b0 b1 b2 1 a1 a2] of scipy.signal.cheby1(order, rp, wn) (even order): conjugate
+    pole pairs, a double zero at z=-1 per section, the gain on the first.  Section order does not change
+    the response (SciPy orders by pole radius)."""
+    eps = np.sqrt(10.0 ** (0.1 * rp) - 1.0)
+    mu = np.arcsinh(1.0 / eps) / order
+    theta = np.pi * np.arange(-order + 1, order, 2) / (2 * order)
+    p = -np.sinh(mu + 1j * theta)                       # analog prototype poles
+    k = np.prod(-p).real
+    if order % 2 == 0:
+        k /= np.sqrt(1.0 + eps * eps)
+    warped = 4.0 * np.tan(np.pi * wn / 2.0)             # pre-warp, fs = 2
+    p = p * warped
+    k = k * warped ** order
+    pz = (4.0 + p) / (4.0 - p)                          # bilinear
+    kz = k * np.real(1.0 / np.prod(4.0 - p))
+    assert order % 2 == 0
+    up = sorted([q for q in pz if q.imag > 0], key=lambda q: abs(q))
+    sos = np.zeros((order // 2, 6))
+    for i, q in enumerate(up):
+        sos[i] = [1.0, 2.0, 1.0, 1.0, -2.0 * q.real, abs(q) ** 2]
+    sos[0, :3] *= kz
+    return sos
+
+
+def sosfilt_zi(sos):
+    """scipy.signal.sosfilt_zi: per-section lfilter_zi (step-response steady state), each scaled by the DC
+    gain of the sections before it."""
+    zi = np.zeros((sos.shape[0], 2))
+    scale = 1.0
+    for s, (b0, b1, b2, a0, a1, a2) in enumerate(sos):
+        # (I - A^T) zi = B with A the companion matrix of a, B = b[1:] - a[1:] b0
+        m = np.array([[1.0 + a1, -1.0], [a2, 1.0]])
+        zi[s] = scale * np.linalg.solve(m, np.array([b1 - a1 * b0, b2 - a2 * b0]))
+        scale *= (b0 + b1 + b2) / (a0 + a1 + a2)
+    return zi
+
+
+def _sosfilt(sos, x, zi):
+    try:
+        from . import c_oracle
+    except ImportError:                                   # imported as a top-level module
+        import c_oracle
+    try:
+        return c_oracle.sosfilt(sos, x, zi)
+    except OSError:
+        y = np.array(x, dtype=np.complex128)
+        z = np.array(zi, dtype=np.complex128)
+        for i in range(y.shape[0]):
+            cur = y[i]
+            for s in range(sos.shape[0]):
+                nw = sos[s, 0] * cur + z[s, 0]
+                z[s, 0] = sos[s, 1] * cur - sos[s, 4] * nw + z[s, 1]
+                z[s, 1] = sos[s, 2] * cur - sos[s, 5] * nw
+                cur = nw
+            y[i] = cur
+        return y, z
+
+
+def decimate_iir(x, q):
+    """scipy.signal.decimate(x, q) as find_channel_offset calls it (signal_utils.py:75-76), in complex128
+    (the reference's recursion runs in the input's complex64)."""
+    if int(q) != q or q < 1:
+        raise ValueError("q must be a positive integer")
+    x = np.asarray(x)
+    sos = cheby1_lowpass_sos(8, 0.05, 0.8 / int(q))
+    edge = 3 * (2 * sos.shape[0] + 1)
+    if x.shape[0] <= edge:
+        raise ValueError("The length of the input vector x must be greater than padlen, which is %d." % edge)
+    xd = x.astype(np.complex128)
+    ext = np.concatenate((2 * xd[0] - xd[edge:0:-1], xd, 2 * xd[-1] - xd[-2:-edge - 2:-1]))
+    zi = sosfilt_zi(sos)
+    y, _ = _sosfilt(sos, ext, zi * ext[0])
+    y = y[::-1]
+    y, _ = _sosfilt(sos, y, zi * y[0])
+    return y[::-1][edge:-edge][::int(q)]
+
+
+def channel_xcorr(B1, B2, nl):
+    """|scipy.signal.correlate(B1, pad(B2, nl), 'valid')| when the padded B2 is the longer input:
+    xc[i] = |sum_l B1[l] conj(B2[l + m2 - m1 + nl - i])|, i = 0 .. m2 + 2 nl - m1."""
+    m1, m2 = B1.shape[0], B2.shape[0]
+    K = m2 + 2 * nl - m1
+    if K < 0:
+        raise ValueError("decimate(s2) padded by nl is shorter than decimate(s1)")
+    size = 1
+    while size < m2 + 2 * nl:
+        size *= 2
+    pad = np.zeros(size, dtype=np.complex128)
+    pad[nl:nl + m2] = B2
+    c = np.fft.ifft(np.fft.fft(pad) * np.conj(np.fft.fft(B1, size)))[:K + 1]     # c[k] = sum_l pad[l+k] conj(B1[l])
+    return np.abs(c[::-1])
+
+
+def find_channel_offset(s1, s2, nd, nl, return_xc=False):
+    """signal_utils.py:73-78."""
+    B1 = decimate_iir(s1, nd)
+    B2 = decimate_iir(s2, nd)
+    xc = channel_xcorr(B1, B2, int(nl))
+    off = (int(np.argmax(xc)) - int(nl)) * int(nd)
+    return (off, xc) if return_xc else off
+
+
+def find_channel_offset_libcalls(s1, s2, nd, nl):
+    """The same three SciPy calls the reference makes (the CPU baseline of the start-up step)."""
+    from scipy import signal
+    B1 = signal.decimate(s1, nd)
+    B2 = np.pad(signal.decimate(s2, nd), (nl, nl), "constant")
+    xc = np.abs(signal.correlate(B1, B2, mode="valid"))
+    return (np.argmax(xc) - nl) * nd

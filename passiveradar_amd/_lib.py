@@ -43,6 +43,12 @@ class FrontendDesc(C.Structure):
                 ("taps_host", C.POINTER(C.c_float))]
 
 
+class IirDesc(C.Structure):
+    _fields_ = [("q", C.c_int32), ("padlen", C.c_int32), ("settle", C.c_int32), ("nzeros", C.c_int32),
+                ("npoles", C.c_int32), ("zeros_host", C.POINTER(C.c_double)),
+                ("poles_host", C.POINTER(C.c_double)), ("gain", C.c_double)]
+
+
 RAW_DTYPES = {"int8": 0, "uint8": 1, "int16": 2, "float32": 3, "complex64": 4}
 
 _lib = None
@@ -88,6 +94,9 @@ _SIGNATURES = {
                                             C.c_double, C.c_void_p]),
     "prc_cfar2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                              C.c_void_p, C.c_int32, C.c_void_p]),
+    "prc_decimate_iir": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(IirDesc), C.c_void_p, C.c_void_p]),
+    "prc_channel_offset": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(IirDesc), C.c_int64,
+                                     C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "prc_xcorr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                             C.c_void_p]),
     "prc_frequency_shift": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,

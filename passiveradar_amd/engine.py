@@ -132,6 +132,64 @@ class LsPlan:
             pass
 
 
+def cheby1_lowpass_zpk(order, rp, wn):
+    """Digital Chebyshev type-I low-pass as scipy.signal.cheby1(order, rp, wn, output='zpk') designs it:
+    analog prototype poles -sinh(mu + j theta_m), cut-off pre-warped to 4 tan(pi wn / 2) (fs = 2), bilinear
+    transform; all zeros at z = -1.  Returns (zeros, poles, gain)."""
+    eps = np.sqrt(10.0 ** (0.1 * rp) - 1.0)
+    mu = np.arcsinh(1.0 / eps) / order
+    theta = np.pi * np.arange(-order + 1, order, 2) / (2 * order)
+    p = -np.sinh(mu + 1j * theta)
+    k = np.prod(-p).real
+    if order % 2 == 0:
+        k /= np.sqrt(1.0 + eps * eps)
+    warped = 4.0 * np.tan(np.pi * wn / 2.0)
+    p = p * warped
+    k = k * warped ** order
+    pz = (4.0 + p) / (4.0 - p)
+    kz = k * np.real(1.0 / np.prod(4.0 - p))
+    return -np.ones(order, dtype=np.complex128), pz, float(kz)
+
+
+class IirDecimator:
+    """prc_iir_desc of scipy.signal.decimate(x, q) with its defaults (ftype='iir', n=8, zero_phase=True):
+    cheby1(8, 0.05, 0.8/q) through sosfiltfilt, whose odd extension is 3*(2*4+1) = 27 samples."""
+
+    def __init__(self, q, order=8):
+        if int(q) != q or q < 1:
+            raise ValueError("q must be a positive integer")       # scipy: operator.index(q)
+        z, p, k = cheby1_lowpass_zpk(order, 0.05, 0.8 / int(q))
+        nsec = (order + 1) // 2
+        self.q = int(q)
+        self.padlen = 3 * (2 * nsec + 1)
+        # |pole|^settle < 1e-9: the recursion's memory, replaced by an explicit constant extension
+        self.settle = int(np.ceil(np.log(1e-9) / np.log(np.abs(p).max()) / 64.0)) * 64
+        self._z = np.ascontiguousarray(np.stack([z.real, z.imag], -1).reshape(-1))
+        self._p = np.ascontiguousarray(np.stack([p.real, p.imag], -1).reshape(-1))
+        d = _lib.IirDesc()
+        d.q, d.padlen, d.settle, d.nzeros, d.npoles, d.gain = self.q, self.padlen, self.settle, z.size, p.size, k
+        d.zeros_host = self._z.ctypes.data_as(C.POINTER(C.c_double))
+        d.poles_host = self._p.ctypes.data_as(C.POINTER(C.c_double))
+        self.desc = d
+
+    def out_len(self, n):
+        return -(-int(n) // self.q)
+
+    def decimate(self, x, n, y, stream=None):
+        """y[j] = sosfiltfilt(x)[j q] (complex64 device buffers)"""
+        check(lib().prc_decimate_iir(_ptr(x), int(n), C.byref(self.desc), _ptr(y), stream))
+
+    def channel_offset(self, s1, n1, s2, n2, nl, xc_out=None, stream=None):
+        """(argmax index, number of lags) of |correlate(decimate(s1), pad(decimate(s2), nl), 'valid')|"""
+        n_xc, am = C.c_int64(), C.c_int64()
+        check(lib().prc_channel_offset(_ptr(s1), int(n1), _ptr(s2), int(n2), C.byref(self.desc), int(nl),
+                                       _ptr(xc_out), C.byref(n_xc), C.byref(am), stream))
+        return am.value, n_xc.value
+
+    def n_lags(self, n1, n2, nl):
+        return self.out_len(n2) + 2 * int(nl) - self.out_len(n1) + 1
+
+
 def resample_design(up, dn):
     """scipy.signal.resample_poly's filter and alignment for signal_utils.resample (signal_utils.py:15-17):
     returns (taps with n_pre_pad leading zeros, float32; n_pre_remove; up; dn) with up/dn reduced."""

@@ -6,7 +6,8 @@ import numpy as np
 from . import _lib, engine
 from ._lib import check, lib
 
-__all__ = ["xcorr", "frequency_shift", "deinterleave_IQ", "resample", "front_end"]
+__all__ = ["xcorr", "frequency_shift", "deinterleave_IQ", "resample", "front_end", "find_channel_offset",
+           "decimate_iir"]
 
 
 def xcorr(s1, s2, nlead, nlag):
@@ -65,6 +66,45 @@ def deinterleave_IQ(interleavedIQ):
     dr.upload(raw)
     check(lib().prc_deinterleave(dr.ptr, _lib.RAW_DTYPES[str(raw.dtype)], n, do.ptr, None))
     return do.download((n,), np.complex64)
+
+
+def decimate_iir(x, q):
+    """scipy.signal.decimate(x, q) with its defaults, as find_channel_offset uses it (signal_utils.py:75-76):
+    zero-phase order-8 Chebyshev-I low-pass, every q-th sample, complex64."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    n = x.shape[0]
+    dec = engine.cached_plan(("iirdec", int(q)), lambda: engine.IirDecimator(q))
+    st = engine.staging()
+    dx = st.get("dec_x", 8 * max(n, 1))
+    dy = st.get("dec_y", 8 * max(dec.out_len(n), 1))
+    dx.upload(x)
+    dec.decimate(dx, n, dy)
+    return dy.download((dec.out_len(n),), np.complex64)
+
+
+def find_channel_offset(s1, s2, nd, nl, return_xc=False):
+    """signal_utils.py:73-78: (argmax|correlate(decimate(s1, nd), pad(decimate(s2, nd), nl), 'valid')| - nl)*nd.
+    With ``return_xc`` also the correlation magnitudes (float32, m2 + 2 nl - m1 + 1 lags)."""
+    s1 = np.ascontiguousarray(s1, dtype=np.complex64)
+    s2 = np.ascontiguousarray(s2, dtype=np.complex64)
+    if s1.ndim != 1 or s2.ndim != 1:
+        raise ValueError("find_channel_offset takes one-dimensional signals")
+    nl = int(nl)
+    dec = engine.cached_plan(("iirdec", int(nd)), lambda: engine.IirDecimator(nd))
+    n1, n2 = s1.shape[0], s2.shape[0]
+    st = engine.staging()
+    d1 = st.get("co_1", 8 * max(n1, 1))
+    d2 = st.get("co_2", 8 * max(n2, 1))
+    d1.upload(s1)
+    d2.upload(s2)
+    dxc = None
+    if return_xc:
+        dxc = st.get("co_xc", 4 * max(dec.n_lags(n1, n2, nl), 1))
+    am, n_xc = dec.channel_offset(d1, n1, d2, n2, nl, dxc)
+    offset = (am - nl) * int(nd)
+    if return_xc:
+        return offset, dxc.download((n_xc,), np.float32)
+    return offset
 
 
 def resample(x, up, dn):

@@ -282,3 +282,41 @@ def test_cfar_golden():
     out = CFAR_2D(torch.from_numpy(stack).cuda(), 18, 4).cpu().numpy()
     assert rel_err(out[0], g["cr_18_4"]) < TIGHT and rel_err(2 * out[1], g["cr_18_4"]) < TIGHT   # numerator is normalised, the box sum is not
     assert rel_err(out[2], O.CFAR_2D(g["X"][::-1], 18, 4)) < TIGHT
+
+
+def test_channel_offset_golden():
+    """SURVEY 8f next #2 on the GPU: spectral zero-phase IIR decimator + rocFFT correlation + argmax against the
+    reference's find_channel_offset outputs (integer offsets identical, |xc| profile to float32 accuracy)."""
+    from passiveradar_amd.signal_utils import decimate_iir, find_channel_offset
+    g = load_golden("channel_offset")
+    for tag in g["cases"]:
+        s1, s2, nd, nl = g[f"{tag}_s1"], g[f"{tag}_s2"], int(g[f"{tag}_nd"]), int(g[f"{tag}_nl"])
+        B1 = decimate_iir(s1, nd)
+        assert B1.dtype == np.complex64 and B1.shape[0] == -(-s1.shape[0] // nd)
+        assert rel_err(B1[:1500], g[f"{tag}_B1_head"]) < 2e-5 and rel_err(B1[-1500:], g[f"{tag}_B1_tail"]) < 2e-5
+        assert rel_err(B1, O.decimate_iir(s1, nd)) < 5e-6
+        off, xc = find_channel_offset(s1, s2, nd, nl, return_xc=True)
+        assert off == int(g[f"{tag}_offset"]), tag
+        assert xc.dtype == np.float32 and xc.shape == g[f"{tag}_xc"].shape
+        assert rel_err(xc, g[f"{tag}_xc"]) < 2e-5
+        assert find_channel_offset(s1, s2, nd, nl) == off
+
+
+def test_channel_offset_edges():
+    from passiveradar_amd.signal_utils import decimate_iir, find_channel_offset
+    with pytest.raises(ValueError):
+        decimate_iir(np.zeros(27, np.complex64), 1)                  # sosfiltfilt: n must exceed padlen
+    with pytest.raises(ValueError):
+        find_channel_offset(np.ones(4000, np.complex64), np.ones(100, np.complex64), 1, 10)   # 'valid' needs the padded s2 longer
+    with pytest.raises(ValueError):
+        find_channel_offset(np.ones(4000, np.complex64), np.ones(4000, np.complex64), 0, 10)
+    # shortest legal input, a real-valued input, nl = 0 (a single lag)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(28).astype(np.float32)
+    assert rel_err(decimate_iir(x, 1), O.decimate_iir(x, 1)) < 5e-6
+    s = (rng.standard_normal(5000) + 1j * rng.standard_normal(5000)).astype(np.complex64)
+    off, xc = find_channel_offset(s, s, 1, 0, return_xc=True)
+    assert off == 0 and xc.shape == (1,)
+    # a delay well past the decimated correlation's noise floor, odd decimation factor
+    s2 = np.roll(s, 333)
+    assert find_channel_offset(s, s2, 3, 200) == O.find_channel_offset(s, s2, 3, 200) == -333

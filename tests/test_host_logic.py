@@ -118,3 +118,21 @@ def test_output_store_roundtrip(tmp_path):
                doppler_cell_width=0.5, meta_fname=str(tmp_path / "m.npz"))
     m = np.load(output.save_metadata(cfg, 5))
     assert m["frame_timestamps"].shape == (5,) and m["range_bins"].shape == (4,) and m["doppler_bins"].shape == (16,)
+
+
+def test_iir_decimator_design_matches_scipy():
+    """host-side filter design handed to prc_channel_offset / prc_decimate_iir (no device call)"""
+    import scipy.signal as sg
+    from passiveradar_amd import engine
+    for q in (1, 2, 4, 7, 10):
+        z, p, k = engine.cheby1_lowpass_zpk(8, 0.05, 0.8 / q)
+        z0, p0, k0 = sg.cheby1(8, 0.05, 0.8 / q, output="zpk")
+        assert np.allclose(np.sort_complex(p), np.sort_complex(p0), rtol=0, atol=1e-13)
+        assert np.allclose(z, z0) and abs(k - k0) <= 1e-12 * abs(k0)
+        d = engine.IirDecimator(q)
+        assert d.padlen == 27 and np.abs(p).max() ** d.settle < 1e-9 and d.settle % 64 == 0
+        assert d.out_len(1001) == -(-1001 // q) and d.n_lags(1001, 1001, 50) == 101
+    with pytest.raises(ValueError):
+        engine.IirDecimator(0)
+    with pytest.raises(ValueError):
+        engine.IirDecimator(2.5)

@@ -171,3 +171,32 @@ def test_cfar_restatement():
     assert rel_err(O.CFAR_2D(g["X"], 7, 2), g["cr_7_2"]) < 1e-12
     det = O.CFAR_2D(g["X"], 18, 4, float(g["thr"]))
     assert det.dtype == bool and np.array_equal(det, g["det_18_4"]) and 5 < det.sum() < 30
+
+
+def test_channel_offset_restatement():
+    """signal.decimate's zero-phase IIR restated (design, steady state, odd extension,
+    recursion) and the 'valid' correlation's index convention, against the reference's outputs."""
+    g = load_golden("channel_offset")
+    for tag in g["cases"]:
+        s1, s2, nd, nl = g[f"{tag}_s1"], g[f"{tag}_s2"], int(g[f"{tag}_nd"]), int(g[f"{tag}_nl"])
+        B1 = O.decimate_iir(s1, nd)
+        # the reference's recursion runs in complex64: a few 1e-6 of rounding noise against the double oracle
+        assert rel_err(B1[:1500], g[f"{tag}_B1_head"]) < 2e-5 and rel_err(B1[-1500:], g[f"{tag}_B1_tail"]) < 2e-5
+        off, xc = O.find_channel_offset(s1, s2, nd, nl, return_xc=True)
+        assert off == int(g[f"{tag}_offset"]), tag
+        assert xc.shape == g[f"{tag}_xc"].shape and rel_err(xc, g[f"{tag}_xc"]) < 2e-5
+        assert O.find_channel_offset_libcalls(s1, s2, nd, nl) == off
+    with pytest.raises(ValueError):
+        O.decimate_iir(np.zeros(27, np.complex64), 1)
+
+
+def test_python_sosfilt_loop_matches_c_twin():
+    from oracle import c_oracle
+    sos = O.cheby1_lowpass_sos(8, 0.05, 0.2)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(300) + 1j * rng.standard_normal(300)
+    zi = O.sosfilt_zi(sos) * x[0]
+    yc, zc = c_oracle.sosfilt(sos, x, zi)
+    import scipy.signal as sg
+    ys, zs = sg.sosfilt(sos, x, zi=zi)
+    assert np.abs(yc - ys).max() < 1e-12 and np.abs(zc - zs).max() < 1e-12
