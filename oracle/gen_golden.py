@@ -301,6 +301,32 @@ def big_cases():
              peak=mag.max())
 
 
+def pipeline_cfg2_case():
+    """BASELINE config 2 end to end, from the reference's own functions: three 1.2 M-sample hop chunks through
+    LS_Filter_Multiple (5 Doppler bins, T=266) and the middle overlapped frame (main.py:169-194 geometry)
+    through fast_xambg with the Kaiser(5) window.  Inputs are regenerated from the seed by the tests."""
+    print("config-2 pipeline frame (LS x5 + CAF at full size)")
+    n, R, F, fs = 2400000, 256, 512, 2.4e6
+    C = n // 2
+    a, s = scene.make_stream(3, C, fs, R, scene.scene_seed(4))
+    t0 = time.time()
+    cleaned = np.concatenate([
+        ref_cr.LS_Filter_Multiple(a[i * C:(i + 1) * C], s[i * C:(i + 1) * C], R, fs, [0, 1, -1, 2, -2])
+        for i in range(3)])
+    print(f"  LS_Filter_Multiple x3 chunks {time.time() - t0:.1f}s")
+    depth = n // 4
+    pad = np.zeros(depth)
+    ap = np.concatenate((pad, a, pad))
+    sp = np.concatenate((pad, cleaned, pad))
+    w = signal.get_window(("kaiser", 5.0), n)
+    t0 = time.time()
+    with no_root_finding():
+        out = ref_rd.fast_xambg(ap[C:C + n], sp[C:C + n], R, F, n, w)
+    print(f"  fast_xambg {time.time() - t0:.1f}s")
+    save("pipeline_cfg2", seed=scene.scene_seed(4), N=n, R=R, F=F, fs=fs, frame_index=1,
+         cleaned_sub=cleaned[::101].astype(np.complex64), out=out[:, :, 0].astype(np.complex64))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also generate the cfg1/2/3 CAF goldens (minutes)")

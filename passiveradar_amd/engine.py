@@ -189,6 +189,9 @@ class IirDecimator:
     def n_lags(self, n1, n2, nl):
         return self.out_len(n2) + 2 * int(nl) - self.out_len(n1) + 1
 
+    def close(self):
+        """nothing device-side to release (the plan cache calls this on eviction)"""
+
 
 def resample_design(up, dn):
     """scipy.signal.resample_poly's filter and alignment for signal_utils.resample (signal_utils.py:15-17):

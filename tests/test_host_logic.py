@@ -136,3 +136,26 @@ def test_iir_decimator_design_matches_scipy():
         engine.IirDecimator(0)
     with pytest.raises(ValueError):
         engine.IirDecimator(2.5)
+
+
+def test_plan_cache_evicts_with_close():
+    """every object the per-thread plan cache can hold must be closable (eviction calls close())"""
+    from passiveradar_amd import engine
+    for cls in (engine.CafPlan, engine.LsPlan, engine.FrontendPlan, engine.IirDecimator):
+        assert callable(getattr(cls, "close", None)), cls
+    closed = []
+
+    class Fake:
+        def __init__(self, k):
+            self.k = k
+
+        def close(self):
+            closed.append(self.k)
+
+    import threading
+    def work():
+        for k in range(5):
+            engine.cached_plan(("fake", k), lambda k=k: Fake(k), limit=3)
+    t = threading.Thread(target=work)
+    t.start(); t.join()
+    assert closed == [0, 1]
