@@ -455,7 +455,7 @@ __device__ __forceinline__ void cmac_bconj(float2& w, float2 u, float2 x) {   //
     w.y = fmaf(-u.x, x.y, w.y);
 }
 
-__global__ __launch_bounds__(64 * LSF_WAVES, 1) void ls_corr_cached_kernel(LsFftArgs a) {
+__global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_cached_kernel(LsFftArgs a) {
     constexpr bool FIRST = true;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
