@@ -4,11 +4,17 @@
 //   u_k[i] = ref[L+k+peek-i], i = 0..T-1;  e = srv[k+L] - w^H u;  w += mu u conj(e) / (u^H u)
 // The recursion is strictly sequential in k; the parallelism is the T taps (spread over the 64
 // lanes of ONE wavefront so that no workgroup barrier sits on the critical path) and the
-// independent streams (one wavefront each, >= 4 per CU).  This is a latency/VALU-bound wavefront
-// dot-product + AXPY loop -- not HBM-bound (24 B/sample) and not MFMA-shaped.
+// independent streams (one wavefront each).  This is a VALU-issue-bound wavefront dot-product +
+// AXPY loop -- not HBM-bound (24 B/sample) and not MFMA-shaped.
+//
+// Placement matters more than anything else here: a SIMD that gets two of these wavefronts while its
+// neighbour gets none runs 1.5x longer, and with one-wavefront workgroups the dispatcher does exactly that
+// on the first launch after a different kernel.  So a workgroup is 4, 8 or 12 independent wavefronts
+// (= 1, 2 or 3 per SIMD) and asks for more than half of the CU's LDS: exactly one workgroup per CU, its
+// wavefronts dealt round-robin to the four SIMDs.  Wavefronts never share LDS data, so there is no
+// workgroup barrier anywhere.
 #include "common.h"
 
-#define NLMS_KT 1024   // steps per staged window
 
 struct NlmsArgs {
     const float2* ref;
@@ -18,6 +24,7 @@ struct NlmsArgs {
     float2* taps_out;        // [nstreams][T] or nullptr
     int64_t n, stride, out_stride;
     int32_t L, peek, T;
+    int32_t nstreams, kt;    // kt: steps per staged LDS window
     float mu;
 };
 
@@ -46,42 +53,66 @@ __device__ __forceinline__ float wave_allsum(float v) {
     return (a + b) + (c + d);
 }
 
-template <int TPL>
-__global__ __launch_bounds__(64) void nlms_kernel(NlmsArgs a) {
+typedef float v2f __attribute__((ext_vector_type(2)));
+// acc += conj(w) * u :  (acc.x, acc.y) += w.x (u.x, u.y);  (acc.x, acc.y) += w.y (u.y, -u.x)
+__device__ __forceinline__ void pk_cmac_conj(v2f& acc, v2f w, v2f u) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n"
+                 "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
+                 : "+v"(acc) : "v"(w), "v"(u));
+}
+// w += u * conj(c) :  (w.x, w.y) += c.x (u.x, u.y);  (w.x, w.y) += c.y (u.y, -u.x)
+__device__ __forceinline__ void pk_cmac_bconj(v2f& w, v2f u, v2f c) {
+    asm("v_pk_fma_f32 %0, %2, %1, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n"
+                 "v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
+                 : "+v"(w) : "v"(u), "v"(c));
+}
+
+// a wavefront only orders its own LDS traffic (the hardware keeps one wavefront's LDS operations in order)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int TPL, int MAXW>
+__global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* Rw = reinterpret_cast<float2*>(smem_raw);   // NLMS_KT + 64*TPL : ref window
-    float2* D = Rw + NLMS_KT + 64 * TPL;                // NLMS_KT : srv in, error out
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x;
+    const int KT = a.kt;
+    const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float2* Rw = reinterpret_cast<float2*>(smem_raw) + (size_t)wave_id * (2 * KT + 64 * TPL);   // KT + 64*TPL : ref window
+    float2* D = Rw + KT + 64 * TPL;                     // KT : srv in, error out
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (int)(blockDim.x >> 6) + wave_id;
+    if (b >= a.nstreams) return;                        // no barriers below: idle wavefronts just leave
     const float2* __restrict__ ref = a.ref + (int64_t)b * a.stride;
     const float2* __restrict__ srv = a.srv + (int64_t)b * a.stride;
     float2* __restrict__ out = a.out + (int64_t)b * a.out_stride;
     const int T = a.T;
     const int64_t nsteps = a.n - T;   // k = 0..nsteps-1 (may be <= 0)
 
-    float2 w[TPL];
+    v2f w[TPL];
 #pragma unroll
     for (int t = 0; t < TPL; ++t) {
         const int i = lane + 64 * t;
-        w[t] = (a.taps_in && i < T) ? a.taps_in[(int64_t)b * T + i] : make_float2(0.f, 0.f);
+        const float2 w0 = (a.taps_in && i < T) ? a.taps_in[(int64_t)b * T + i] : make_float2(0.f, 0.f);
+        w[t] = v2f{w0.x, w0.y};
     }
     // out[0:L] = 0 and out[n-peek:] = 0 (:231)
     for (int64_t i = lane; i < a.n; i += 64)
         if (i < a.L || i >= a.L + (nsteps > 0 ? nsteps : 0)) out[i] = make_float2(0.f, 0.f);
 
     const int WIN = 64 * TPL;   // >= T; taps i >= T are held at zero through zero u
-    for (int64_t k0 = 0; k0 < nsteps; k0 += NLMS_KT) {
+    for (int64_t k0 = 0; k0 < nsteps; k0 += KT) {
         const int64_t rem = nsteps - k0;
-        const int cnt = rem < NLMS_KT ? (int)rem : NLMS_KT;
-        __syncthreads();
+        const int cnt = rem < KT ? (int)rem : KT;
+        wave_lds_fence();
         // window element x <-> ref[k0 + 1 - (WIN - T) + x];  u_kk[i] = Rw[kk + WIN - 1 - i]
         const int64_t base = k0 + 1 - (WIN - T);
-        for (int x = lane; x < NLMS_KT + WIN; x += 64) {
+        for (int x = lane; x < KT + WIN; x += 64) {
             const int64_t idx = base + x;
             Rw[x] = (idx >= 0 && idx < a.n) ? ref[idx] : make_float2(0.f, 0.f);
         }
         for (int x = lane; x < cnt; x += 64) D[x] = srv[k0 + x + a.L];
-        __syncthreads();
+        wave_lds_fence();
         // u^H u is summed exactly at the start of every staged window and then slid:
         //   E(k+1) = E(k) + |ref[T+k+1]|^2 - |ref[k+1]|^2      (window element kk+WIN enters, kk+WIN-T leaves)
         float energy;
@@ -98,24 +129,23 @@ __global__ __launch_bounds__(64) void nlms_kernel(NlmsArgs a) {
         // One step: dot (registers), two DPP reductions, AXPY.  The sliding window of the NEXT step
         // is fetched from LDS while this step reduces (ua/ub swap roles, loop unrolled by two), so
         // the only latency left on the critical path is the reduction itself.
-        auto fetch = [&](float2 (&u)[TPL], int kk) {
+        auto fetch = [&](v2f (&u)[TPL], int kk) {
 #pragma unroll
             for (int t = 0; t < TPL; ++t) {
                 const int i = lane + 64 * t;
                 float2 v = Rw[kk + WIN - 1 - i];
                 if (t == TPL - 1 && i >= T) v = make_float2(0.f, 0.f);   // only the last group can overhang T
-                u[t] = v;
+                u[t] = v2f{v.x, v.y};
             }
         };
-        auto step = [&](const float2 (&u)[TPL], float2 (&unext)[TPL], int kk) {
-            float yr = 0.f, yi = 0.f;
+        auto step = [&](const v2f (&u)[TPL], v2f (&unext)[TPL], int kk) {
+            // conj(w) * u on packed FMAs (one wavefront per SIMD only reaches half the scalar-FMA issue rate; the
+            // packed form runs at full rate), four independent accumulators to keep the chains short
+            v2f acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-            for (int t = 0; t < TPL; ++t) {          // conj(w) * u
-                yr = fmaf(w[t].x, u[t].x, yr);
-                yr = fmaf(w[t].y, u[t].y, yr);
-                yi = fmaf(w[t].x, u[t].y, yi);
-                yi = fmaf(-w[t].y, u[t].x, yi);
-            }
+            for (int t = 0; t < TPL; ++t) pk_cmac_conj(acc[t & 3], w[t], u[t]);
+            const v2f ysum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            float yr = ysum.x, yi = ysum.y;
             fetch(unext, kk + 1);                    // independent of this step's result
             yr = wave_allsum(yr);
             yi = wave_allsum(yi);
@@ -127,17 +157,12 @@ __global__ __launch_bounds__(64) void nlms_kernel(NlmsArgs a) {
             const float2 d = D[kk];
             const float er = d.x - yr, ei = d.y - yi;
             const float s = a.mu / en;               // coefficient mu * conj(e) / (u^H u)
-            const float cr = er * s, ci = -ei * s;
+            const v2f c = {er * s, ei * s};         // w += u * conj(c')  with c' = (er, ei) s  (mu conj(e) / (u^H u))
 #pragma unroll
-            for (int t = 0; t < TPL; ++t) {
-                w[t].x = fmaf(cr, u[t].x, w[t].x);
-                w[t].x = fmaf(-ci, u[t].y, w[t].x);
-                w[t].y = fmaf(cr, u[t].y, w[t].y);
-                w[t].y = fmaf(ci, u[t].x, w[t].y);
-            }
+            for (int t = 0; t < TPL; ++t) pk_cmac_bconj(w[t], u[t], c);
             if (lane == 0) D[kk] = make_float2(er, ei);
         };
-        float2 ua[TPL], ub[TPL];
+        v2f ua[TPL], ub[TPL];
         fetch(ua, 0);
         int kk = 0;
         for (; kk + 2 <= cnt; kk += 2) {
@@ -145,14 +170,14 @@ __global__ __launch_bounds__(64) void nlms_kernel(NlmsArgs a) {
             step(ub, ua, kk + 1);
         }
         if (kk < cnt) step(ua, ub, kk);
-        __syncthreads();
+        wave_lds_fence();
         for (int x = lane; x < cnt; x += 64) out[a.L + k0 + x] = D[x];
     }
     if (a.taps_out) {
 #pragma unroll
         for (int t = 0; t < TPL; ++t) {
             const int i = lane + 64 * t;
-            if (i < T) a.taps_out[(int64_t)b * T + i] = w[t];
+            if (i < T) a.taps_out[(int64_t)b * T + i] = make_float2(w[t].x, w[t].y);
         }
     }
 }
@@ -182,24 +207,44 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
     a.peek = peek;
     a.T = T;
     a.mu = mu;
-#define PRC_NLMS_CASE(G)                                                                        \
+    a.nstreams = nstreams;
+    // wavefronts per workgroup = per CU: one per SIMD up to 1024 streams, then two, then three (register file permitting)
+    const int maxw = tpl <= 17 ? 12 : (tpl <= 24 ? 8 : 4);
+    // measured step time of a SIMD holding 1 / 2 / 3 of these wavefronts, relative: 1.0 / 1.55 / 2.2 (MI355X)
+    int nw = 4;
+    double best = 1e30;
+    for (int w = 4; w <= maxw; w += 4) {
+        const double rounds = (double)ceil_div64(ceil_div64(nstreams, w), 256);
+        const double cost = rounds * (w == 4 ? 1.0 : (w == 8 ? 1.55 : 2.2));
+        if (cost < best) { best = cost; nw = w; }
+    }
+    const size_t lds_cu = 160 * 1024;
+    int kt = 1024;
+    while (kt > 64 && (size_t)nw * (2 * kt + 64 * tpl) * sizeof(float2) > lds_cu) kt >>= 1;
+    a.kt = kt;
+    size_t lds = (size_t)nw * (2 * kt + 64 * tpl) * sizeof(float2);
+    PRC_REQUIRE(lds <= lds_cu, PRC_EUNSUPPORTED, "prc_nlms_execute: %d taps do not fit the LDS window", T);
+    if (lds < 84 * 1024) lds = 84 * 1024;              // more than half a CU's LDS: one workgroup per CU
+    const int grid = (int)ceil_div64(nstreams, nw);
+#define PRC_NLMS_CASE(G, W)                                                                     \
     if (tpl <= G) {                                                                             \
-        size_t lds = sizeof(float2) * (NLMS_KT + 64 * G + NLMS_KT);                             \
-        hipLaunchKernelGGL(nlms_kernel<G>, dim3(nstreams), dim3(64), lds, (hipStream_t)stream, a); \
+        PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nlms_kernel<G, W>),          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu));  \
+        hipLaunchKernelGGL((nlms_kernel<G, W>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, a); \
         PRC_LAUNCH_CHECK();                                                                     \
         return PRC_OK;                                                                          \
     }
-    PRC_NLMS_CASE(1)
-    PRC_NLMS_CASE(2)
-    PRC_NLMS_CASE(3)
-    PRC_NLMS_CASE(4)
-    PRC_NLMS_CASE(5)
-    PRC_NLMS_CASE(6)
-    PRC_NLMS_CASE(8)
-    PRC_NLMS_CASE(12)
-    PRC_NLMS_CASE(17)
-    PRC_NLMS_CASE(24)
-    PRC_NLMS_CASE(32)
+    PRC_NLMS_CASE(1, 12)
+    PRC_NLMS_CASE(2, 12)
+    PRC_NLMS_CASE(3, 12)
+    PRC_NLMS_CASE(4, 12)
+    PRC_NLMS_CASE(5, 12)
+    PRC_NLMS_CASE(6, 12)
+    PRC_NLMS_CASE(8, 12)
+    PRC_NLMS_CASE(12, 12)
+    PRC_NLMS_CASE(17, 12)
+    PRC_NLMS_CASE(24, 8)
+    PRC_NLMS_CASE(32, 4)
 #undef PRC_NLMS_CASE
     return PRC_EUNSUPPORTED;
 }

@@ -124,7 +124,8 @@ class HipBackend:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         # pipelining doubles the latency-bound solve launches; it only pays once they are amortised
         self.overlap = bool(overlap) and clutter == "ls" and self.batch >= 128
-        self.sub = -(-self.batch // max(int(nsub), 1)) if self.overlap else self.batch   # chunks per LS launch
+        # chunks per LS launch; NLMS is one wavefront per chunk, so splitting a batch would only idle SIMDs
+        self.sub = -(-self.batch // max(int(nsub), 1)) if (self.overlap and clutter == "ls") else self.batch
         with torch.cuda.device(self.device):
             self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch, caf_method, doppler_method)
             self.ls = engine.LsPlan(self.C, self.R, 10, False, self.sub, ls_method) if clutter == "ls" else None

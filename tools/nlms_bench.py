@@ -3,7 +3,7 @@ sys.path.insert(0,'.')
 from passiveradar_amd import engine, _lib
 dev=torch.device('cuda')
 n=200000; L=1024
-for ns in (1, 256, 1024, 2048, 3072, 4096):
+for ns in (1, 256, 1024, 1026, 2048, 3072, 4096):
     g=torch.Generator(device=dev); g.manual_seed(1)
     ref=torch.view_as_complex(torch.randn((ns*n,2),generator=g,device=dev))
     srv=torch.roll(ref,2)+0.01*torch.view_as_complex(torch.randn((ns*n,2),generator=g,device=dev))
