@@ -623,17 +623,23 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
     const unsigned vo8 = (unsigned)lane * 8u;
     const unsigned vslot = vo8 - (unsigned)ext * 8u;
 
-    float2 h[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int idx = 64 * r + lane;
-        const double2 t = taps[idx < T ? idx : 0];
-        h[r] = idx < T ? make_float2((float)t.x, (float)t.y) : make_float2(0.f, 0.f);
-    }
-    fft1024_fwd(h, tile, tab, f);
+    // H~ = FFT(taps)/1024 of this block: made once by wave 0, shared by the workgroup through LDS (keeping it in
+    // registers costs 32 VGPRs per lane for the whole kernel and pushes the compiler into scratch spills)
+    float2* Hs = tab + FFTW_TABLE + LSF_WAVES * FFTW_TILE;
     const float sc = 1.0f / 1024.0f;
+    if (wave_id == 0) {
+        float2 h[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { h[r].x *= sc; h[r].y *= sc; }
+        for (int r = 0; r < 16; ++r) {
+            const int idx = 64 * r + lane;
+            const double2 t = taps[idx < T ? idx : 0];
+            h[r] = idx < T ? make_float2((float)t.x, (float)t.y) : make_float2(0.f, 0.f);
+        }
+        fft1024_fwd(h, tile, tab, f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Hs[64 * r + lane] = make_float2(h[r].x * sc, h[r].y * sc);
+    }
+    __syncthreads();
 
     float2 wrs[16];
 #pragma unroll
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
             fft1024_fwd(xc, tile, tab, f);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = cmul(xc[r], h[r]);
+        for (int r = 0; r < 16; ++r) y[r] = cmul(xc[r], Hs[64 * r + lane]);
         __builtin_amdgcn_sched_barrier(0);
         issue_x(p + nwaves);
         {
@@ -839,7 +845,7 @@ int ls_launch_fused_cached(LsFftArgs a, double theta, double theta_next, double 
     int rc = fftw_device_tables(&a.tab);
     if (rc) return rc;
     dim3 grid((unsigned)(waves_per_block / LSF_WAVES), (unsigned)nblocks);
-    const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE);
+    const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE + FFTW_P);
     if (a.cache)
         hipLaunchKernelGGL(ls_fused_cached_kernel<true>, grid, dim3(64 * LSF_WAVES), lds, stream, a);
     else
