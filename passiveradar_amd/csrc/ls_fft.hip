@@ -478,9 +478,12 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_cached_kernel(LsFft
     const unsigned vslot = vo8 - (unsigned)ext * 8u;          // slot idx -> piece sample idx-ext (idx<ext: out of range)
     const __amdgpu_buffer_rsrc_t rx = prc_rsrc(ref + peek, lsf_clampu(n - peek) * 8u);
 
-    float2 wrr[16], wrs[16];
+    // the autocorrelation accumulator lives in LDS (one 8 KB strip per wave, read-modify-write once per piece):
+    // with it in registers the kernel does not fit two waves per SIMD without scratch spills
+    float2* Wrr = tab + FFTW_TABLE + LSF_WAVES * FFTW_TILE + wave_id * FFTW_P;
+    float2 wrs[16];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) { wrr[m] = make_float2(0.f, 0.f); wrs[m] = make_float2(0.f, 0.f); }
+    for (int m = 0; m < 16; ++m) { Wrr[64 * m + lane] = make_float2(0.f, 0.f); wrs[m] = make_float2(0.f, 0.f); }
 
     float2 xn[16];                                            // block of the next piece (prefetched)
     auto issue_x = [&](int p) {
@@ -560,7 +563,11 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_cached_kernel(LsFft
             }
             fft1024_fwd(up, tile, tab, f);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) cmac_bconj(wrr[m], up[m], x[m]);
+            for (int m = 0; m < 16; ++m) {
+                float2 t = Wrr[64 * m + lane];
+                cmac_bconj(t, up[m], x[m]);
+                Wrr[64 * m + lane] = t;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (a.rot) {
@@ -577,8 +584,11 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_cached_kernel(LsFft
 #pragma unroll
         for (int m = 0; m < 16; ++m) cmac_bconj(wrs[m], u[m], x[m]);
     }
-    if (FIRST) fft1024_inv(wrr, tile, tab, f);
     fft1024_inv(wrs, tile, tab, f);
+    float2 wrr[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wrr[m] = Wrr[64 * m + lane];
+    if (FIRST) fft1024_inv(wrr, tile, tab, f);
     // partial[b][wave][0/1][lag] holds conj(g): the prepare / solve prologues conjugate back
     float2* __restrict__ part = a.partial + ((int64_t)b * nwaves + wg) * 2 * T;
     const float sc = 1.0f / 1024.0f;
@@ -828,7 +838,9 @@ int ls_launch_corr_cached(LsFftArgs a, double theta, int waves_per_block, int nb
     int rc = fftw_device_tables(&a.tab);
     if (rc) return rc;
     dim3 grid((unsigned)(waves_per_block / LSF_WAVES), (unsigned)nblocks);
-    const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE);
+    const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE + LSF_WAVES * FFTW_P);
+    PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ls_corr_cached_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     hipLaunchKernelGGL(ls_corr_cached_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
     PRC_LAUNCH_CHECK();
     return PRC_OK;
