@@ -26,6 +26,8 @@ void fftw_make_tables(float2* t) {
         for (int j = 0; j < 4; ++j) {
             const double a = -2.0 * PI * (double)(m * j) / 64.0;
             t[FFTW_TW1 + 4 * m + j] = make_float2((float)cos(a), (float)sin(a));
+            const float sg = (j == 0 || j == 3) ? 1.f : -1.f;          // sA_j sB_j, see fft_wave.h
+            t[FFTW_TW1 + FFTW_TW2 + 4 * m + j] = make_float2(sg * (float)cos(a), sg * (float)sin(a));
         }
 }
 

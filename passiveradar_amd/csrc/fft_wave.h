@@ -24,7 +24,8 @@
 #define FFTW_TILE (16 * FFTW_PITCH)   // float2 elements per wave tile
 #define FFTW_TW1 (16 * 64)        // W_1024^(n2*k1), [k1][n2]
 #define FFTW_TW2 (16 * 4)         // W_64^(j*m'),    [m'][j]
-#define FFTW_TABLE (FFTW_TW1 + FFTW_TW2)
+#define FFTW_TW2S (16 * 4)        // the same times the quad sign sigma_j = sA_j sB_j (forward transform)
+#define FFTW_TABLE (FFTW_TW1 + FFTW_TW2 + FFTW_TW2S)
 
 __device__ __forceinline__ float2 f2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 f2sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -100,6 +101,7 @@ __device__ __forceinline__ float dpp_quad_xor1(float x) {   // quad_perm [1,0,3,
 struct FftLane {
     float sA;   // +1 for quad lanes 0,1; -1 for lanes 2,3   (stage over lane^2)
     float sB;   // +1 for even quad lanes; -1 for odd        (stage over lane^1)
+    float sg;   // sA * sB
     bool l3;    // quad lane 3 carries the -i twiddle
     int rd_off; // (lane>>2)*PITCH + (lane&3)  : quad-strided tile address
     int lane;
@@ -111,6 +113,7 @@ __device__ __forceinline__ FftLane fft_lane_setup() {
     const int j = f.lane & 3;
     f.sA = (j < 2) ? 1.f : -1.f;
     f.sB = (j & 1) ? -1.f : 1.f;
+    f.sg = f.sA * f.sB;
     f.l3 = (j == 3);
     f.rd_off = (f.lane >> 2) * FFTW_PITCH + j;
     return f;
@@ -122,23 +125,53 @@ __device__ __forceinline__ void fft_load_tables(float2* lds_tab, const float2* _
     for (int i = threadIdx.x; i < FFTW_TABLE; i += blockDim.x) lds_tab[i] = gtab[i];
 }
 
-// radix-4 across the quad, forward (DIF): lane j ends with X[bitrev2(j)]
-template <int DIR>
-__device__ __forceinline__ float2 quad_dft4_fwd(float2 c, const FftLane& f) {
-    float2 t = make_float2(dpp_quad_xor2(c.x), dpp_quad_xor2(c.y));
-    float2 r = make_float2(fmaf(f.sA, c.x, t.x), fmaf(f.sA, c.y, t.y));
-    if (f.l3) r = mul_mi<DIR>(r);
-    t = make_float2(dpp_quad_xor1(r.x), dpp_quad_xor1(r.y));
-    return make_float2(fmaf(f.sB, r.x, t.x), fmaf(f.sB, r.y, t.y));
+// Radix-4 across the four lanes of a quad, two butterflies r = s c + c_partner with a per-lane sign s.
+// Written on the sign-scaled value U = s' c the butterfly is ONE VOP2-DPP instruction,
+//     d += dpp(d) * (-s)        (v_fmac_f32_dpp: the partner's value arrives through the DPP operand),
+// because the partner's sign is the opposite of one's own.  The scaling is free: it is folded into the twiddle
+// that precedes the stage (forward, table TW2S) or into the caller's pointwise product (inverse, PRESCALED).
+//   forward : U = sg c;  R = U - sA dpp_xor2(U) = sB (sA c + c_p);  lane 3: R *= -i;  X = R - sB dpp_xor1(R)
+//   inverse : P = sg y;  R = P - sB dpp_xor1(P) = sA (sB y + y_p);  lane 3: R *= +i;  x = R - sA dpp_xor2(R)
+// Eight elements (16 VGPRs) per asm block.  A DPP operand read needs two wait states after the VALU write of
+// that register (the twiddle multiply / the lane-3 select just before); the compiler cannot see that these
+// instructions are DPP, so each block opens with s_nop 1.
+#define FFTW_DPP_LINE(n, perm) "v_fmac_f32_dpp %" #n ", %" #n ", -%16 quad_perm:" perm " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define FFTW_DPP_BLOCK(perm)                                                                               \
+    "s_nop 1\n" FFTW_DPP_LINE(0, perm) FFTW_DPP_LINE(1, perm) FFTW_DPP_LINE(2, perm) FFTW_DPP_LINE(3, perm)  \
+    FFTW_DPP_LINE(4, perm) FFTW_DPP_LINE(5, perm) FFTW_DPP_LINE(6, perm) FFTW_DPP_LINE(7, perm)             \
+    FFTW_DPP_LINE(8, perm) FFTW_DPP_LINE(9, perm) FFTW_DPP_LINE(10, perm) FFTW_DPP_LINE(11, perm)           \
+    FFTW_DPP_LINE(12, perm) FFTW_DPP_LINE(13, perm) FFTW_DPP_LINE(14, perm) FFTW_DPP_LINE(15, perm)
+#define FFTW_DPP_OPERANDS(x, o)                                                                                      \
+    "+v"(x[o].x), "+v"(x[o].y), "+v"(x[o + 1].x), "+v"(x[o + 1].y), "+v"(x[o + 2].x), "+v"(x[o + 2].y),             \
+    "+v"(x[o + 3].x), "+v"(x[o + 3].y), "+v"(x[o + 4].x), "+v"(x[o + 4].y), "+v"(x[o + 5].x), "+v"(x[o + 5].y),     \
+    "+v"(x[o + 6].x), "+v"(x[o + 6].y), "+v"(x[o + 7].x), "+v"(x[o + 7].y)
+// x[m] -= s * x[m][lane ^ 2] (XOR2) or [lane ^ 1] for all 16 registers
+template <bool XOR2>
+__device__ __forceinline__ void quad_bfly(float2 (&x)[16], float s) {
+    if (XOR2) {
+        asm(FFTW_DPP_BLOCK("[2,3,0,1]") : FFTW_DPP_OPERANDS(x, 0) : "v"(s));
+        asm(FFTW_DPP_BLOCK("[2,3,0,1]") : FFTW_DPP_OPERANDS(x, 8) : "v"(s));
+    } else {
+        asm(FFTW_DPP_BLOCK("[1,0,3,2]") : FFTW_DPP_OPERANDS(x, 0) : "v"(s));
+        asm(FFTW_DPP_BLOCK("[1,0,3,2]") : FFTW_DPP_OPERANDS(x, 8) : "v"(s));
+    }
 }
-// exact mirror (unnormalised x4): lane j holds X[bitrev2(j)] in, time-side quad index j out
+template <int DIR>
+__device__ __forceinline__ void quad_dft4_fwd(float2 (&u)[16], const FftLane& f) {   // u = sg * c
+    quad_bfly<true>(u, f.sA);
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        if (f.l3) u[m] = mul_mi<DIR>(u[m]);
+    quad_bfly<false>(u, f.sB);
+}
+// exact mirror (unnormalised x4): lane j holds sg * X[bitrev2(j)] in, time-side quad index j out
 template <int DIR>   // DIR is the direction of the *transform* (-1 for the inverse FFT)
-__device__ __forceinline__ float2 quad_dft4_bwd(float2 y, const FftLane& f) {
-    float2 t = make_float2(dpp_quad_xor1(y.x), dpp_quad_xor1(y.y));
-    float2 r = make_float2(fmaf(f.sB, y.x, t.x), fmaf(f.sB, y.y, t.y));
-    if (f.l3) r = mul_mi<DIR>(r);
-    t = make_float2(dpp_quad_xor2(r.x), dpp_quad_xor2(r.y));
-    return make_float2(fmaf(f.sA, r.x, t.x), fmaf(f.sA, r.y, t.y));
+__device__ __forceinline__ void quad_dft4_bwd(float2 (&p)[16], const FftLane& f) {   // p = sg * y
+    quad_bfly<false>(p, f.sB);
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+        if (f.l3) p[m] = mul_mi<DIR>(p[m]);
+    quad_bfly<true>(p, f.sA);
 }
 
 // Forward FFT: natural (lane n2, reg n1) -> permuted frequency layout.
@@ -154,18 +187,24 @@ __device__ __forceinline__ void fft1024_fwd(float2 (&x)[16], float2* tile, const
     for (int m = 0; m < 16; ++m) x[m] = tile[f.rd_off + 4 * m];
     __builtin_amdgcn_wave_barrier();
     dft16<1>(x);
-    const float2* tw2 = tab + FFTW_TW1 + (f.lane & 3);
+    const float2* tw2s = tab + FFTW_TW1 + FFTW_TW2 + (f.lane & 3);   // sigma_j W_64^(j m')
+    x[0].x *= f.sg;
+    x[0].y *= f.sg;
 #pragma unroll
-    for (int m = 1; m < 16; ++m) x[m] = mul_tw<1>(x[m], tw2[4 * m]);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) x[m] = quad_dft4_fwd<1>(x[m], f);
+    for (int m = 1; m < 16; ++m) x[m] = mul_tw<1>(x[m], tw2s[4 * m]);
+    quad_dft4_fwd<1>(x, f);
 }
 
 // Inverse FFT (unnormalised): permuted frequency layout -> natural (lane n2, reg n1).
+// PRESCALED: the caller already multiplied the spectrum by the lane's quad sign f.sg (e.g. folded into a filter).
+template <bool PRESCALED = false>
 __device__ __forceinline__ void fft1024_inv(float2 (&x)[16], float2* tile, const float2* tab,
                                             const FftLane& f) {
+    if (!PRESCALED) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) x[m] = quad_dft4_bwd<-1>(x[m], f);
+        for (int m = 0; m < 16; ++m) { x[m].x *= f.sg; x[m].y *= f.sg; }
+    }
+    quad_dft4_bwd<-1>(x, f);
     const float2* tw2 = tab + FFTW_TW1 + (f.lane & 3);
 #pragma unroll
     for (int m = 1; m < 16; ++m) x[m] = mul_tw<-1>(x[m], tw2[4 * m]);

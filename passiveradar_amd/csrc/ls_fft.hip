@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fir_fft_kernel(LsFftArgs
         h[r] = idx < T ? make_float2((float)t.x, (float)t.y) : make_float2(0.f, 0.f);
     }
     fft1024_fwd(h, tile, tab, f);
-    const float sc = 1.0f / 1024.0f;
+    const float sc = f.sg * (1.0f / 1024.0f);        // 1/1024 and the inverse FFT's quad sign (PRESCALED)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { h[r].x *= sc; h[r].y *= sc; }
 
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fir_fft_kernel(LsFftArgs
         __builtin_amdgcn_sched_barrier(0);
         issue_x(p + nwaves);
         __builtin_amdgcn_sched_barrier(0);
-        fft1024_inv(x, tile, tab, f);
+        fft1024_inv<true>(x, tile, tab, f);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int idx = 64 * r + lane;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fir_fft_lin_kernel(LsFft
         h[r] = idx < T ? make_float2((float)t.x, (float)t.y) : make_float2(0.f, 0.f);
     }
     fft1024_fwd(h, tile, tab, f);
-    const float sc = 1.0f / 1024.0f;
+    const float sc = f.sg * (1.0f / 1024.0f);        // 1/1024 and the inverse FFT's quad sign (PRESCALED)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { h[r].x *= sc; h[r].y *= sc; }
 
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fir_fft_lin_kernel(LsFft
             for (int r = 0; r < 16; ++r) sv[r] = prc_buf_load_c64(rs, vout + 512u * r, 0u);
         }
         __builtin_amdgcn_sched_barrier(0);
-        fft1024_inv(x, tile, tab, f);
+        fft1024_inv<true>(x, tile, tab, f);
         const __amdgpu_buffer_rsrc_t ro = prc_rsrc(out + n0, lsf_clampu(cnt) * 8u);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
         }
         fft1024_fwd(h, tile, tab, f);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Hs[64 * r + lane] = make_float2(h[r].x * sc, h[r].y * sc);
+        for (int r = 0; r < 16; ++r) Hs[64 * r + lane] = make_float2(h[r].x * sc * f.sg, h[r].y * sc * f.sg);   // quad sign of the inverse FFT folded in
     }
     __syncthreads();
 
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
             sbase.y = -sbase.y;
         }
         __builtin_amdgcn_sched_barrier(0);
-        fft1024_inv(y, tile, tab, f);
+        fft1024_inv<true>(y, tile, tab, f);
         // last `peek` outputs of the block: rho samples whose ramp restarted carry gamma instead of 1
         if (a.rot && peek > 0 && n0 + cnt > n - peek) {
             const float2 g1 = a.gamma_m1;
