@@ -16,7 +16,9 @@ line = open(os.path.join(src, "bench_line.json")).read().strip()
 bench = json.loads(line)
 rows = list(csv.DictReader(open(os.path.join(src, "trace", "bench_kernel_stats.csv"))))
 shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_cfg2_kernel_stats.csv"))
-json.dump(bench, open(os.path.join(dst, f"{tag}_bench_default.json"), "w"), indent=1)
+full = os.path.join(src, "bench_full_line.json")       # the untraced default run (with the CPU baseline), if collected
+json.dump(json.loads(open(full).read()) if os.path.exists(full) else bench,
+          open(os.path.join(dst, f"{tag}_bench_default.json"), "w"), indent=1)
 
 PMC_FRAMES, NSUB_UNITS = 64, 64          # the PMC passes run --frames 64: one LS launch covers 64 hop chunks
 def pmc(counter):
