@@ -380,6 +380,7 @@ struct LsSolveArgs {
     double2* taps_t;         // [block][T]  w~[k] = w[k] e^{-j theta k}  (what the cached FIR applies)
     int64_t n;
     int32_t nblk, T, nref, peek;
+    int32_t srv_rotated;     // the stream already is s~ = s e^{-j theta (n+peek)} (bins after the first of a chain)
     double theta;            // rotation of this bin (effective float32 ramp slope)
 };
 
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(LSS_THREADS) void ls_solve_kernel(LsSolveArgs a) {
             for (int64_t m = a.n - a.peek; m + k < a.n; ++m) {
                 const float2 r = rr[m + a.peek - a.n];
                 const float2 sraw = ss[m + k];
-                const double2 st = zmul(make_double2(sraw.x, sraw.y), ph);
+                const double2 st = a.srv_rotated ? make_double2(sraw.x, sraw.y) : zmul(make_double2(sraw.x, sraw.y), ph);
                 eb = zadd(eb, zmul(make_double2(r.x, -r.y), st));
                 ph = zmul(ph, dph);
             }
@@ -695,6 +696,7 @@ static void fill_xa(LsFftArgs& xa, prc_ls_plan* p, const void* ref, int64_t stri
     xa.pr = pr;
     xa.has_next = 0;
     xa.rot2 = 0;
+    xa.rot_in = 0;
     xa.pr2 = pr;
 }
 
@@ -720,6 +722,7 @@ static int run_cached_chain(prc_ls_plan* p, const void* ref, const void* srv, in
         sa.n = n;  sa.nblk = p->nblk;  sa.T = T;  sa.peek = p->desc.peek;
         // effective slope of the reference's float32 ramp: fl32(2 pi f) * fl32(1/Fs)
         sa.theta = pr.enabled ? (double)pr.a32 * (double)pr.rcp32 : 0.0;
+        sa.srv_rotated = i > 0 ? 1 : 0;                // fused(i-1) stored its output in this bin's frame
         // one refinement squares the wrap perturbation (~ a few peek/N); two for shorter blocks; none
         // when the ramp closes on itself over the block (gamma = e^{-j theta N} = 1: c_f = D c_0 exactly)
         const double gm1 = hypot(cos(sa.theta * (double)n) - 1.0, sin(sa.theta * (double)n));
@@ -763,11 +766,14 @@ static int run_cached_chain(prc_ls_plan* p, const void* ref, const void* srv, in
         const int64_t dst_stride = has_next ? n : out_stride;
         LsFftArgs xa;
         fill_xa(xa, p, ref, stride, cur, cur_stride, dst, dst_stride, pr);
-        double theta_next = 0.0;
+        // the stream this bin reads is in its own rotated frame unless it is still the caller's raw input;
+        // it is written in the next bin's frame (the last bin writes the true output, frame 0)
+        xa.rot_in = (ib == 0 && pr.enabled) ? 1 : 0;
+        double theta_out = 0.0;
         if (has_next) {
             const PhaseRamp prn = make_ramp(bins[ib + 1], sample_rate, 0.0);
-            theta_next = theta_exact(ib + 1);
-            PRC_REQUIRE(!prn.enabled || fabs(theta_next) * (p->desc.peek + 1) <= 0.3, PRC_EUNSUPPORTED,
+            theta_out = theta_exact(ib + 1);
+            PRC_REQUIRE(!prn.enabled || fabs(theta_out) * (p->desc.peek + 1) <= 0.3, PRC_EUNSUPPORTED,
                         "prc_ls_execute: |2 pi fc/Fs| * peek too large for the FFT kernels (use method=1)");
             xa.has_next = 1;
             xa.rot2 = prn.enabled;
@@ -775,7 +781,7 @@ static int run_cached_chain(prc_ls_plan* p, const void* ref, const void* srv, in
         }
         const double theta_eff = pr.enabled ? (double)pr.a32 * (double)pr.rcp32 : 0.0;
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
-        rc = ls_launch_fused_cached(xa, theta_exact(ib), theta_next, -theta_eff * (double)n, p->fft_waves,
+        rc = ls_launch_fused_cached(xa, theta_exact(ib), theta_out, -theta_eff * (double)n, p->fft_waves,
                                     nblocks, stream);
         if (rc) return rc;
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 3], stream));

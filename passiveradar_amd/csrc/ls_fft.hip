@@ -609,7 +609,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_cached_kernel(LsFft
 // CACHED: X_p = FFT(rho block p) is read from the spectrum cache (8 KB per block).  !CACHED: it is
 // recomputed from the reference (6 KB per block + L2-served overlap, one more FFT): fewer HBM bytes,
 // more VALU -- the kernel is HBM-bound, so this is the default.
-template <bool CACHED>
+template <bool CACHED, bool ROT_IN>
 __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
@@ -705,11 +705,16 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
 #pragma unroll
             for (int r = 0; r < 16; ++r) sv[r] = prc_buf_load_c64(rs, vslot + 512u * r, 0u);
         }
-        float2 obase = make_float2(1.f, 0.f), sbase = make_float2(1.f, 0.f);
-        if (a.rot) obase = phase_rot(a.pr, (int64_t)n0 - ext + lane + peek);
-        if (a.rot2) {
-            sbase = phase_rot(a.pr2, (int64_t)n0 - ext + lane + peek);
-            sbase.y = -sbase.y;
+        // one rotation on the way out: from this bin's frame to the frame of whoever reads the stream next
+        const bool rot_out = a.rot || a.rot2;
+        float2 obase = make_float2(1.f, 0.f), ibase = make_float2(1.f, 0.f);
+        if (rot_out) {
+            const int64_t idx = (int64_t)n0 - ext + lane + peek;
+            const float2 p1 = a.rot ? phase_rot(a.pr, idx) : make_float2(1.f, 0.f);
+            float2 p2 = a.rot2 ? phase_rot(a.pr2, idx) : make_float2(1.f, 0.f);
+            p2.y = -p2.y;
+            obase = cmul(p1, p2);
+            if (ROT_IN) ibase = make_float2(p1.x, -p1.y);
         }
         __builtin_amdgcn_sched_barrier(0);
         fft1024_inv<true>(y, tile, tab, f);
@@ -735,21 +740,23 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
         const __amdgpu_buffer_rsrc_t ro = prc_rsrc(out + n0, lsf_clampu(cnt) * 8u);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float2 yy = y[r];
-            if (a.rot) yy = cmul(yy, cmul(obase, a.step[r]));
-            const float2 o = make_float2(sv[r].x - yy.x, sv[r].y - yy.y);
+            float2 sin_ = sv[r];
+            if (ROT_IN) {                                   // raw input, rotated bin: s~ = s e^{-j phi_i}
+                float2 st = a.step2[r];
+                st.y = -st.y;
+                sin_ = cmul(sin_, cmul(ibase, st));
+            }
+            float2 o = make_float2(sin_.x - y[r].x, sin_.y - y[r].y);
+            if (rot_out) o = cmul(o, cmul(obase, a.step[r]));
             prc_v2u d;
             d.x = __float_as_uint(o.x);
             d.y = __float_as_uint(o.y);
             __builtin_amdgcn_raw_buffer_store_b64(d, ro, (int)(vslot + 512u * r), 0, 0);
-            // the cleaned piece stays in registers as the next bin's surveillance piece:
-            // slots [ext, ext+cnt) only (the other slots of y are circular-convolution garbage)
+            // the stored piece (already in the next bin's frame) stays in registers as that bin's correlation
+            // input: slots [ext, ext+cnt) only (the other slots of y are circular-convolution garbage)
             const int idx = 64 * r + lane;
             const bool in = idx >= ext && idx < ext + cnt;
-            float2 st = a.step2[r];
-            st.y = -st.y;
-            const float2 sr = a.rot2 ? cmul(o, cmul(sbase, st)) : o;
-            y[r] = in ? sr : make_float2(0.f, 0.f);
+            y[r] = in ? o : make_float2(0.f, 0.f);
         }
         if (a.has_next) {
             fft1024_fwd(y, tile, tab, f);
@@ -846,22 +853,27 @@ int ls_launch_corr_cached(LsFftArgs a, double theta, int waves_per_block, int nb
     return PRC_OK;
 }
 
-int ls_launch_fused_cached(LsFftArgs a, double theta, double theta_next, double gamma_angle, int waves_per_block,
+int ls_launch_fused_cached(LsFftArgs a, double theta, double theta_out, double gamma_angle, int waves_per_block,
                            int nblocks, hipStream_t stream) {
     fill_common(a, a.T, theta);
     for (int r = 0; r < 16; ++r) {
-        const double ang = theta_next * 64.0 * r;
-        a.step2[r] = make_float2((float)cos(ang), (float)sin(ang));
+        const double ang_in = theta * 64.0 * r, ang = (theta - theta_out) * 64.0 * r;
+        a.step2[r] = make_float2((float)cos(ang_in), (float)sin(ang_in));
+        a.step[r] = make_float2((float)cos(ang), (float)sin(ang));
     }
     a.gamma_m1 = make_float2((float)(cos(gamma_angle) - 1.0), (float)sin(gamma_angle));
     int rc = fftw_device_tables(&a.tab);
     if (rc) return rc;
     dim3 grid((unsigned)(waves_per_block / LSF_WAVES), (unsigned)nblocks);
     const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE + FFTW_P);
-    if (a.cache)
-        hipLaunchKernelGGL(ls_fused_cached_kernel<true>, grid, dim3(64 * LSF_WAVES), lds, stream, a);
-    else
-        hipLaunchKernelGGL(ls_fused_cached_kernel<false>, grid, dim3(64 * LSF_WAVES), lds, stream, a);
+    const dim3 block(64 * LSF_WAVES);
+    if (a.cache) {
+        if (a.rot_in) hipLaunchKernelGGL((ls_fused_cached_kernel<true, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((ls_fused_cached_kernel<true, false>), grid, block, lds, stream, a);
+    } else {
+        if (a.rot_in) hipLaunchKernelGGL((ls_fused_cached_kernel<false, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((ls_fused_cached_kernel<false, false>), grid, block, lds, stream, a);
+    }
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }

@@ -17,8 +17,14 @@ struct LsFftArgs {
     PhaseRamp pr;
     float theta32;           // 2 pi fc / Fs (phase of the <= peek samples that wrapped to index 0)
     float2 step[16];         // exp(j theta 64 r): per-register phase step of the Doppler rotation
-    // fused FIR(bin i) + correlation(bin i+1) kernel: rotation of the NEXT bin and gamma_i - 1
-    int32_t has_next, rot2;
+    // fused FIR(bin i) + correlation(bin i+1) kernel.  The streams between the bins of a chain are private to
+    // it and are kept in the ROTATED frame of the bin that reads them (value = s e^{-j phi_bin(n)}): the kernel
+    // subtracts the unrotated FIR output directly and applies ONE rotation e^{j(phi_i - phi_out)} on the way out
+    // (phi_out: the next bin's ramp, or 0 for the last bin) instead of one for the FIR and one for the next
+    // correlation.  pr2/rot2 describe phi_out; step[] is overwritten with exp(j (theta_i - theta_out) 64 r);
+    // rot_in: the input is still the caller's raw stream and bin i is rotated (first bin only), step2[] =
+    // exp(j theta_i 64 r) then.
+    int32_t has_next, rot2, rot_in;
     PhaseRamp pr2;
     float2 step2[16];
     float2 gamma_m1;
@@ -32,5 +38,5 @@ int ls_launch_fir_fft(LsFftArgs a, double theta, int nblocks, hipStream_t stream
 // cached-spectrum chain (linear boundary): first bin builds the cache, later bins and every FIR reuse it
 int64_t ls_cache_elems_per_block(int64_t n, int T);
 int ls_launch_corr_cached(LsFftArgs a, double theta, int waves_per_block, int nblocks, hipStream_t stream);
-int ls_launch_fused_cached(LsFftArgs a, double theta, double theta_next, double gamma_angle, int waves_per_block,
+int ls_launch_fused_cached(LsFftArgs a, double theta, double theta_out, double gamma_angle, int waves_per_block,
                            int nblocks, hipStream_t stream);

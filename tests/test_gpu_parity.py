@@ -320,3 +320,15 @@ def test_channel_offset_edges():
     # a delay well past the decimated correlation's noise floor, odd decimation factor
     s2 = np.roll(s, 333)
     assert find_channel_offset(s, s2, 3, 200) == O.find_channel_offset(s, s2, 3, 200) == -333
+
+
+def test_ls_chain_first_bin_rotated():
+    """cached multi-bin chain whose FIRST Doppler bin is non-zero: the caller's raw stream has to be taken into
+    that bin's rotated frame on the way in (every later bin reads a stream already stored in its own frame)"""
+    from passiveradar_amd.clutter_removal import LS_Filter_Multiple
+    n, L, fs = 40000, 24, 1.0e4
+    ref, srv = scene.make_scene(n, fs, L, 4711, targets=((11, 3.0, 0.05),))
+    for bins in ([2, 0, -1], [-3, 3], [1, 1, 0]):
+        exp = O.LS_Filter_Multiple(ref, srv, L, fs, bins)
+        got = LS_Filter_Multiple(ref, srv, L, fs, bins)
+        assert rel_err(got, exp) < TOL, bins
