@@ -145,7 +145,14 @@ def main():
     srv_pad = be.padded(srv)
     del ref, srv
     nill = N_ILLUMINATORS.get(args.workload, 1)
-    extra_refs = [be.padded(synth_stream(torch, B, C, fs, R, 777 + 13 * i + rank, device)[0]) for i in range(nill - 1)]
+    # further illuminators (cfg5): independent white references; the surveillance channel carries every
+    # illuminator's scene
+    extra_refs = []
+    for i in range(nill - 1):
+        er, es = synth_stream(torch, B, C, fs, R, 777 + 13 * i + rank, device)
+        extra_refs.append(be.padded(er))
+        srv_pad += be.padded(es)
+        del er, es
     shard = prstream.Shard(rank, world, B * world, rank * B, (rank + 1) * B, 0, B)
 
     pending = []                                   # (frames kept alive, result, work) of the gather in flight
@@ -276,6 +283,7 @@ def main():
                        "parallelism": f"frame-sharded x{world}, RCCL gather of maps" if world > 1 else "single GPU"},
             "hbm_algorithmic_GBps": per_frame_bytes * value / world / 1e9,
             "hbm_frac_of_peak": per_frame_bytes * value / world / 1e9 / HBM_PEAK_GBS,
+            "hbm_frac_of_copy_ceiling": per_frame_bytes * value / world / 1e9 / 6290.0,   # MI355X_MICROARCH.md: ~6.3 TB/s achievable
             "kernels": {k_: {"avg_ms_per_launch": v["ms"], "launches_per_step": v["launches_per_step"],
                              "algorithmic_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k_, v in kt.items()},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
