@@ -953,7 +953,7 @@ extern "C" int prc_xcorr(const void* s1, const void* s2, int64_t n, int32_t nlea
                          void* out, void* stream_) {
     PRC_REQUIRE(s1 && s2 && out, PRC_EINVAL, "prc_xcorr: null argument");
     PRC_REQUIRE(n > 0 && nlead >= 0 && nlag >= 0, PRC_EINVAL, "prc_xcorr: bad size");
-    PRC_REQUIRE(nlead < n && nlag < n, PRC_EINVAL, "prc_xcorr: lag span exceeds the signal");
+    // lags beyond the signal length are legal (signal_utils.py:29-32 pads s2 by nlag / nlead zeros): their sums are 0
     hipStream_t stream = (hipStream_t)stream_;
     const int nblk = (int)ceil_div64(n, LSC_BLK);
     const int maxl = (nlag > nlead ? nlag : nlead) + 1;

@@ -544,8 +544,12 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_cached_kernel(LsFft
                 for (int r = 0; r < 16; ++r) up[r] = prc_buf_load_c64(ru, vslot + 512u * r, 0u);
                 const int wst = n - peek - n0;                // first wrapped sample of the piece
                 if (peek > 0 && wst < cnt) {
-                    const __amdgpu_buffer_rsrc_t rw = prc_rsrc(ref, lsf_clampu(cnt - wst) * 8u);
-                    const unsigned voff = vslot - (unsigned)wst * 8u;
+                    // a last piece shorter than peek starts inside the wrapped run (wst < 0): the source then
+                    // starts at ref[-wst], not at ref[0] -- otherwise the slots below `ext` would pick up the
+                    // wrapped samples that belong to the previous piece and count them twice
+                    const int w0 = wst > 0 ? wst : 0;
+                    const __amdgpu_buffer_rsrc_t rw = prc_rsrc(ref + (w0 - wst), lsf_clampu(cnt - w0) * 8u);
+                    const unsigned voff = vslot - (unsigned)w0 * 8u;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float2 w = prc_buf_load_c64(rw, voff + 512u * r, 0u);

@@ -226,25 +226,27 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
     PRC_REQUIRE(lds <= lds_cu, PRC_EUNSUPPORTED, "prc_nlms_execute: %d taps do not fit the LDS window", T);
     if (lds < 84 * 1024) lds = 84 * 1024;              // more than half a CU's LDS: one workgroup per CU
     const int grid = (int)ceil_div64(nstreams, nw);
+    // one instantiation per taps-per-lane count: the kernel masks only the LAST 64-tap group against T, so the
+    // group count must be exact (a coarser bucket list once left whole groups beyond T unmasked)
 #define PRC_NLMS_CASE(G, W)                                                                     \
-    if (tpl <= G) {                                                                             \
+    case G: {                                                                                   \
         PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nlms_kernel<G, W>),          \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu));  \
         hipLaunchKernelGGL((nlms_kernel<G, W>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, a); \
         PRC_LAUNCH_CHECK();                                                                     \
         return PRC_OK;                                                                          \
     }
-    PRC_NLMS_CASE(1, 12)
-    PRC_NLMS_CASE(2, 12)
-    PRC_NLMS_CASE(3, 12)
-    PRC_NLMS_CASE(4, 12)
-    PRC_NLMS_CASE(5, 12)
-    PRC_NLMS_CASE(6, 12)
-    PRC_NLMS_CASE(8, 12)
-    PRC_NLMS_CASE(12, 12)
-    PRC_NLMS_CASE(17, 12)
-    PRC_NLMS_CASE(24, 8)
-    PRC_NLMS_CASE(32, 4)
+    switch (tpl) {
+        PRC_NLMS_CASE(1, 12) PRC_NLMS_CASE(2, 12) PRC_NLMS_CASE(3, 12) PRC_NLMS_CASE(4, 12)
+        PRC_NLMS_CASE(5, 12) PRC_NLMS_CASE(6, 12) PRC_NLMS_CASE(7, 12) PRC_NLMS_CASE(8, 12)
+        PRC_NLMS_CASE(9, 12) PRC_NLMS_CASE(10, 12) PRC_NLMS_CASE(11, 12) PRC_NLMS_CASE(12, 12)
+        PRC_NLMS_CASE(13, 12) PRC_NLMS_CASE(14, 12) PRC_NLMS_CASE(15, 12) PRC_NLMS_CASE(16, 12)
+        PRC_NLMS_CASE(17, 12) PRC_NLMS_CASE(18, 8) PRC_NLMS_CASE(19, 8) PRC_NLMS_CASE(20, 8)
+        PRC_NLMS_CASE(21, 8) PRC_NLMS_CASE(22, 8) PRC_NLMS_CASE(23, 8) PRC_NLMS_CASE(24, 8)
+        PRC_NLMS_CASE(25, 4) PRC_NLMS_CASE(26, 4) PRC_NLMS_CASE(27, 4) PRC_NLMS_CASE(28, 4)
+        PRC_NLMS_CASE(29, 4) PRC_NLMS_CASE(30, 4) PRC_NLMS_CASE(31, 4) PRC_NLMS_CASE(32, 4)
+        default: break;
+    }
 #undef PRC_NLMS_CASE
     return PRC_EUNSUPPORTED;
 }

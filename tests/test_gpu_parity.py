@@ -332,3 +332,28 @@ def test_ls_chain_first_bin_rotated():
         exp = O.LS_Filter_Multiple(ref, srv, L, fs, bins)
         got = LS_Filter_Multiple(ref, srv, L, fs, bins)
         assert rel_err(got, exp) < TOL, bins
+
+
+@pytest.mark.parametrize("L", [54, 55, 118, 375, 390, 438, 439, 600, 1014, 1015, 1200, 1700, 2038])
+def test_nlms_every_tap_group_count(L):
+    """one kernel instantiation per 64-tap group count: T = L + 10 on both sides of group boundaries and in the
+    middle of what used to be coarse buckets (7, 10, 19, 27 groups), where whole groups beyond T must stay zero"""
+    from oracle import c_oracle
+    from passiveradar_amd.clutter_removal import NLMS_filter
+    n = L + 10 + 1500
+    ref, srv = scene.make_scene(n, 1e4, 50, 9000 + L)
+    out, taps = NLMS_filter(ref, srv, L, 0.05, 10, None, True)
+    exp, etaps = c_oracle.nlms(ref, srv, L, 0.05, 10)
+    assert rel_err(out, exp) < TOL and rel_err(taps, etaps) < TOL
+
+
+@pytest.mark.parametrize("tail", [1, 5, 9, 10])
+def test_ls_chain_last_piece_shorter_than_peek(tail):
+    """cached chain, block length = 30 overlap-save pieces + `tail` samples: with tail < peek the run of `peek`
+    wrapped reference samples straddles the last two pieces (they were once counted twice in the autocorrelation)"""
+    from passiveradar_amd.clutter_removal import LS_Filter_Multiple
+    L, fs = 48, 1.0e4
+    n = 30 * (1025 - (L + 10)) + tail
+    ref, srv = scene.make_scene(n, fs, 50, 12345)
+    for bins in ([0, 0], [0, 2], [2, 0, -1]):
+        assert rel_err(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)) < 5e-6, bins

@@ -1,0 +1,65 @@
+"""Randomised differential check of the drop-ins against the oracle (GPU box): random shapes around the edges the
+kernels switch on (FFT vs direct CAF, lag blocking, cached vs per-bin LS chain, NLMS taps-per-lane buckets)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from oracle import np_oracle as O, c_oracle
+from passiveradar_amd import scene
+from passiveradar_amd.clutter_removal import LS_Filter, LS_Filter_Multiple, LS_Filter_Toeplitz, NLMS_filter
+from passiveradar_amd.range_doppler_processing import fast_xambg
+from passiveradar_amd.signal_utils import find_channel_offset, xcorr
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 90.0
+rng = np.random.default_rng(seed)
+rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-30))
+worst, fails, ncase = {}, [], 0
+t0 = time.time()
+def note(kind, err, tol, desc):
+    global ncase
+    ncase += 1
+    worst[kind] = max(worst.get(kind, 0.0), err)
+    if not (err < tol):
+        fails.append((kind, err, desc))
+while time.time() - t0 < budget:
+    k = rng.integers(0, 6)
+    if k == 0:      # CAF
+        F = int(rng.choice([2, 8, 16, 51, 64, 128]))
+        N = int(rng.integers(max(2 * F, 600), 40000))
+        R = int(rng.integers(1, min(300, N // 3)))
+        ref, srv = scene.make_scene(N, 1e4, R, int(rng.integers(1 << 30)))
+        win = rng.choice([None, "arr"])
+        w = None if win is None else np.kaiser(N, 3.0)
+        note("caf", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("caf", N, R, F, win))
+    elif k == 1:    # LS Toeplitz / direct
+        N = int(rng.integers(300, 30000)); L = int(rng.integers(1, min(200, N // 8))); peek = int(rng.integers(0, 12))
+        ref, srv = scene.make_scene(N, 1e4, max(L, 50), int(rng.integers(1 << 30)))
+        if rng.random() < 0.5:
+            got, gt = LS_Filter_Toeplitz(ref, srv, L, peek, True); exp, et = O.LS_Filter_Toeplitz(ref, srv, L, peek, True)
+            note("ls_toeplitz", max(rel(got, exp), rel(gt, et)), 1e-4, ("toep", N, L, peek))
+        else:
+            reg = float(rng.choice([0.0, 1.0, 10.0]))
+            got = LS_Filter(ref, srv, L, reg, peek); exp = O.LS_Filter(ref, srv, L, reg, peek)
+            note("ls_direct", rel(got, exp), 1e-4, ("direct", N, L, reg, peek))
+    elif k == 2:    # LS multiple (cached chain when N >= 20000)
+        N = int(rng.integers(2000, 60000)); L = int(rng.integers(2, 120))
+        fs = float(rng.choice([1e4, 2.4e5, 2.4e6]))
+        nb = int(rng.integers(1, 6)); bins = [float(b) for b in rng.integers(-3, 4, nb)]
+        ref, srv = scene.make_scene(N, fs, max(L, 50), int(rng.integers(1 << 30)))
+        note("ls_multiple", rel(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)), 1e-4, ("multi", N, L, fs, bins))
+    elif k == 3:    # NLMS
+        N = int(rng.integers(200, 6000)); L = int(rng.integers(1, 2030)); mu = float(rng.choice([0.01, 0.05, 0.2]))
+        ref, srv = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
+        note("nlms", rel(NLMS_filter(ref, srv, L, mu), c_oracle.nlms(ref, srv, L, mu)[0]) if N > L + 10 else 0.0, 1e-4, ("nlms", N, L, mu))
+    elif k == 4:    # xcorr
+        N = int(rng.integers(100, 50000)); nlead = int(rng.integers(0, 40)); nlag = int(rng.integers(1, 300))
+        a, b = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
+        note("xcorr", rel(xcorr(a, b, nlead, nlag), O.xcorr(a, b, nlead, nlag)), 2e-5, ("xcorr", N, nlead, nlag))
+    else:           # channel offset
+        N = int(rng.integers(2000, 40000)); nd = int(rng.choice([1, 1, 2, 4])); nl = int(rng.integers(10, 3000)); sh = int(rng.integers(-nl // 2, nl // 2 + 1))
+        a = scene.white_reference(N + 8000, int(rng.integers(1 << 30)))
+        s1, s2 = a[4000:4000 + N], a[4000 - sh:4000 - sh + N]
+        note("chan_offset", 0.0 if find_channel_offset(s1, s2, nd, nl) == O.find_channel_offset(s1, s2, nd, nl) else 1.0, 0.5, ("off", N, nd, nl, sh))
+print(f"{ncase} random cases in {time.time() - t0:.0f} s; worst relative error per kind:", {k: f"{v:.1e}" for k, v in worst.items()})
+print("FAILURES:", fails if fails else "none")
+sys.exit(1 if fails else 0)
