@@ -422,6 +422,9 @@ def resample(x, up, dn):
     polyphase sum:  y[m] = sum_j h[(t mod up) + up j] xe[t div up - j],  t = (m + n_pre_remove) dn,
     xe = x extended linearly through its first and last sample (upfirdn mode 'line')."""
     x = np.asarray(x)
+    from math import gcd
+    if int(up) // gcd(int(up), int(dn)) == 1 and int(dn) // gcd(int(up), int(dn)) == 1:
+        return x.copy()                                   # resample_poly: "if up == down == 1: return x.copy()"
     hp, n_pre_remove, up, dn = resample_design(up, dn)
     n_in = x.shape[0]
     n_out = n_in * up

@@ -74,8 +74,25 @@ extern "C" int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int3
     PRC_REQUIRE(fw * fw != gw * gw, PRC_EINVAL, "prc_cfar2d: fw^2 == gw^2 divides by zero (as in the reference)");
     hipStream_t stream = (hipStream_t)stream_;
     const int np = 64;
-    float* d_partial = nullptr;
-    PRC_HIP(hipMallocAsync((void**)&d_partial, sizeof(float) * np * nframes, stream));
+    // per host thread scratch for the |X| partial sums, grown on demand and kept (stream-ordered pool allocation
+    // -- hipMallocAsync / hipFreeAsync -- intermittently handed the block to a later call while this one's
+    // kernels were still queued: whole maps came back scaled by a wrong mean)
+    struct Scratch { float* p = nullptr; size_t cap = 0; int dev = -1; };
+    static thread_local Scratch sc;
+    int dev = 0;
+    PRC_HIP(hipGetDevice(&dev));
+    const size_t need = sizeof(float) * (size_t)np * (size_t)nframes;
+    if (sc.dev != dev || sc.cap < need) {
+        if (sc.p) {
+            PRC_HIP(hipDeviceSynchronize());
+            (void)hipFree(sc.p);
+            sc.p = nullptr;
+        }
+        PRC_HIP(hipMalloc((void**)&sc.p, need));
+        sc.cap = need;
+        sc.dev = dev;
+    }
+    float* d_partial = sc.p;
     hipLaunchKernelGGL(cfar_abs_partial_kernel, dim3(np, nframes), dim3(256), 0, stream, X, (int64_t)H * W, d_partial);
     int e1 = (fw - gw) / 2, e2 = fw - e1 + 1;
     if (e1 < 0) e1 = 0;
@@ -86,7 +103,6 @@ extern "C" int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int3
     hipLaunchKernelGGL(cfar_kernel, grid, dim3(CF_TX * CF_TY), lds, stream, X, H, W, fw, e1, e2,
                        1.0f / (float)(fw * fw - gw * gw), d_partial, np, thresh, use_thresh, out);
     hipError_t le = hipGetLastError();
-    (void)hipFreeAsync(d_partial, stream);
     if (le != hipSuccess) { prc_set_error("prc_cfar2d: launch failed: %s", hipGetErrorString(le)); return PRC_EHIP; }
     return PRC_OK;
 }

@@ -30,6 +30,7 @@ struct FeArgs {
     int64_t n_out;
     int32_t up, dn, J, n_pre_remove;
     int32_t mix;              // apply the frequency shift
+    int32_t opw;              // outputs per workgroup (<= FE_THREADS; fewer when the decimation ratio is large)
     PhaseRamp pr;
 };
 
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FeArgs a) {
     for (int i = tid; i < a.J * a.up; i += FE_THREADS) H[i] = a.taps[i];
 
     // outputs of this workgroup and the input span they touch
-    const int64_t m0 = (int64_t)blockIdx.x * FE_THREADS;
-    int64_t m1 = m0 + FE_THREADS;
+    const int64_t m0 = (int64_t)blockIdx.x * a.opw;
+    int64_t m1 = m0 + a.opw;
     if (m1 > a.n_out) m1 = a.n_out;
     const int64_t i_hi = ((m1 - 1 + a.n_pre_remove) * a.dn) / a.up;      // newest input of the last output
     const int64_t i_lo = ((m0 + a.n_pre_remove) * a.dn) / a.up - (a.J - 1);
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FeArgs a) {
     }
     __syncthreads();
     const int64_t m = m0 + tid;
-    if (m >= a.n_out) return;
+    if (tid >= a.opw || m >= a.n_out) return;
     const int64_t t = (m + a.n_pre_remove) * a.dn;
     const int phase = (int)(t % a.up);
     const int base = (int)(t / a.up - i_lo);          // X index of the newest input of this output
@@ -199,12 +200,20 @@ extern "C" int prc_frontend_execute(prc_frontend_plan* p, const void* raw, int64
     a.pr.rcp32 = 1.0f / (float)fs;
     a.pr.off32 = 0.f;
     a.pr.enabled = a.mix;
-    // staged span per workgroup: FE_THREADS outputs * dn/up inputs + J taps of history
-    const int64_t span = ((int64_t)FE_THREADS * a.dn) / a.up + a.J + 4;
-    const size_t lds = sizeof(float) * ((size_t)(a.J * a.up + 1) & ~(size_t)1) + sizeof(float2) * (size_t)span;
+    // staged span per workgroup: opw outputs * dn/up inputs + J taps of history; opw shrinks (in steps of one
+    // wavefront) until the span fits the CU's LDS, so any decimation ratio runs
+    const size_t lds_taps = sizeof(float) * ((size_t)(a.J * a.up + 1) & ~(size_t)1);
+    a.opw = FE_THREADS;
+    size_t lds = 0;
+    for (;;) {
+        const int64_t span = ((int64_t)a.opw * a.dn) / a.up + a.J + 4;
+        lds = lds_taps + sizeof(float2) * (size_t)span;
+        if (lds <= 150 * 1024 || a.opw <= 1) break;
+        a.opw = a.opw > 64 ? a.opw - 64 : a.opw / 2;
+    }
     PRC_REQUIRE(lds <= 160 * 1024, PRC_EUNSUPPORTED, "prc_frontend_execute: resampling ratio %d/%d needs %zu B of LDS",
                 a.up, a.dn, lds);
-    dim3 grid((unsigned)ceil_div64(p->n_out, FE_THREADS), (unsigned)nblocks);
+    dim3 grid((unsigned)ceil_div64(p->n_out, a.opw), (unsigned)nblocks);
 #define PRC_FE_CASE(S)                                                                               \
     case S:                                                                                          \
         (void)hipFuncSetAttribute((const void*)frontend_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \

@@ -112,6 +112,10 @@ def resample(x, up, dn):
     The stream is complex64 on the device; the result is returned in the input's dtype (the reference
     keeps complex128 when fed the tuned complex128 stream)."""
     xin = np.asarray(x)
+    from math import gcd
+    g = gcd(int(up), int(dn))
+    if int(up) // g == 1 and int(dn) // g == 1:
+        return xin.copy()                                  # scipy.signal.resample_poly: up == down -> a copy
     xc = np.ascontiguousarray(xin, dtype=np.complex64)
     n = xc.shape[0]
     plan = engine.cached_plan(("fe", n, "complex64", int(up), int(dn)),

@@ -7,7 +7,8 @@ from oracle import np_oracle as O, c_oracle
 from passiveradar_amd import scene
 from passiveradar_amd.clutter_removal import LS_Filter, LS_Filter_Multiple, LS_Filter_Toeplitz, NLMS_filter
 from passiveradar_amd.range_doppler_processing import fast_xambg
-from passiveradar_amd.signal_utils import find_channel_offset, xcorr
+from passiveradar_amd.signal_utils import decimate_iir, deinterleave_IQ, find_channel_offset, frequency_shift, front_end, resample, xcorr
+from passiveradar_amd.target_detection import CFAR_2D
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 90.0
@@ -22,7 +23,7 @@ def note(kind, err, tol, desc):
     if not (err < tol):
         fails.append((kind, err, desc))
 while time.time() - t0 < budget:
-    k = rng.integers(0, 6)
+    k = rng.integers(0, 11)
     if k == 0:      # CAF
         F = int(rng.choice([2, 8, 16, 51, 64, 128]))
         N = int(rng.integers(max(2 * F, 600), 40000))
@@ -55,6 +56,33 @@ while time.time() - t0 < budget:
         N = int(rng.integers(100, 50000)); nlead = int(rng.integers(0, 40)); nlag = int(rng.integers(1, 300))
         a, b = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
         note("xcorr", rel(xcorr(a, b, nlead, nlag), O.xcorr(a, b, nlead, nlag)), 2e-5, ("xcorr", N, nlead, nlag))
+    elif k == 6:    # big CAF: several lag blocks, long CPIs
+        F = int(rng.choice([4, 32, 100])); N = int(rng.integers(20000, 300000)); R = int(rng.integers(200, 1200))
+        ref, srv = scene.make_scene(N, 1e5, R, int(rng.integers(1 << 30)))
+        note("caf_big", rel(fast_xambg(ref, srv, R, F), c_oracle.fast_xambg(ref, srv, R, F)), 2e-5, ("cafbig", N, R, F))
+    elif k == 7:    # LS near the FFT-kernel limit (T - 1 <= 768) and long blocks
+        N = int(rng.integers(20000, 200000)); L = int(rng.choice([200, 500, 740, 758, 759, 760, 800]))
+        fs = 2.4e6; bins = [0.0, 1.0, -1.0][:int(rng.integers(1, 4))]
+        ref, srv = scene.make_scene(N, fs, 100, int(rng.integers(1 << 30)))
+        note("ls_long", rel(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)), 1e-4, ("lslong", N, L, bins))
+    elif k == 8:    # front end pieces
+        n = int(rng.integers(100, 30000))
+        dt = rng.choice(["int8", "uint8", "int16", "float32"])
+        raw = (rng.standard_normal(2 * n) * 30).astype(dt)
+        ok = np.array_equal(deinterleave_IQ(raw), O.deinterleave_IQ(raw))
+        x = O.deinterleave_IQ(raw)[:max(n // 2, 40)]
+        up, dn = int(rng.integers(1, 20)), int(rng.integers(1, 130))
+        e1 = rel(resample(x, up, dn), O.resample(x, up, dn))
+        fc = float(rng.uniform(-2e5, 2e5)); e2 = rel(frequency_shift(x, fc, 2.4e6, 0.3), O.frequency_shift(x, fc, 2.4e6, 0.3))
+        note("front_end", max(e1, e2, 0.0 if ok else 1.0), 2e-5, ("fe", n, dt, up, dn, fc))
+    elif k == 9:    # CFAR
+        H, W = int(rng.integers(20, 300)), int(rng.integers(20, 300)); fw = int(rng.integers(3, 19)); gw = int(rng.integers(0, fw - 1))
+        X = np.abs(rng.standard_normal((H, W))).astype(np.float32) + 0.1
+        note("cfar", rel(CFAR_2D(X, fw, gw), O.CFAR_2D(X, fw, gw)), 2e-5, ("cfar", H, W, fw, gw))
+    elif k == 10:   # zero-phase IIR decimator
+        n = int(rng.integers(28, 60000)); q = int(rng.choice([1, 2, 3, 4, 5, 8, 10]))
+        x = scene.white_reference(n, int(rng.integers(1 << 30)))
+        note("decimate_iir", rel(decimate_iir(x, q), O.decimate_iir(x, q)), 2e-5, ("dec", n, q))
     else:           # channel offset
         N = int(rng.integers(2000, 40000)); nd = int(rng.choice([1, 1, 2, 4])); nl = int(rng.integers(10, 3000)); sh = int(rng.integers(-nl // 2, nl // 2 + 1))
         a = scene.white_reference(N + 8000, int(rng.integers(1 << 30)))
