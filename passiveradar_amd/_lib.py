@@ -106,6 +106,30 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 under
+    torch/lib (same SONAMEs as /opt/rocm's).  Whichever copy is loaded first serves every later user of that
+    SONAME: if libprcore pulled in /opt/rocm's first, a later ``import torch`` would run on a runtime it was not
+    built with and report "No HIP GPUs are available".  So when torch is installed but not imported yet, its copy
+    is loaded first (without importing torch) -- the configuration every GPU test runs in."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libprcore.so once; raise (never fall back) if it is not built."""
     global _lib
@@ -117,6 +141,7 @@ def lib():
                 raise ImportError(
                     f"{LIB_PATH} is not built: run `make -C passiveradar_amd/csrc` (hipcc, gfx950). "
                     "passiveradar_amd has no CPU fallback.")
+            _share_hip_runtime_with_torch()
             handle = C.CDLL(LIB_PATH)
             for name, (res, args) in _SIGNATURES.items():
                 fn = getattr(handle, name)

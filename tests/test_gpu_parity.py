@@ -5,6 +5,7 @@ Tolerance: north_star states float32 parity as max|X_gpu - X_ref| / max|X_ref| <
 on white-reference scenes; TOL below is that bar.  The tighter TIGHT bar documents what the
 kernels actually achieve (fp32 accumulation of <= ~5000-term sums).
 """
+import os
 import numpy as np
 import pytest
 
@@ -357,3 +358,26 @@ def test_ls_chain_last_piece_shorter_than_peek(tail):
     ref, srv = scene.make_scene(n, fs, 50, 12345)
     for bins in ([0, 0], [0, 2], [2, 0, -1]):
         assert rel_err(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)) < 5e-6, bins
+
+
+def test_library_first_then_torch_in_a_fresh_process():
+    """import order must not matter: libprcore used before torch is imported (fresh interpreter), then torch must
+    still see the GPU and the device-tensor path must agree with the NumPy path (one HIP runtime per process)"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, '.')\n"
+        "from passiveradar_amd import scene\n"
+        "from passiveradar_amd.range_doppler_processing import fast_xambg\n"
+        "assert 'torch' not in sys.modules\n"
+        "ref, srv = scene.make_scene(8192, 1e4, 20, 1)\n"
+        "X = fast_xambg(ref, srv, 20, 32)\n"
+        "import torch\n"
+        "assert torch.cuda.is_available() and torch.cuda.device_count() >= 1\n"
+        "Xt = fast_xambg(torch.from_numpy(ref).cuda(), torch.from_numpy(srv).cuda(), 20, 32)\n"
+        "assert float(np.abs(Xt.cpu().numpy() - X).max()) == 0.0\n"
+        "print('ok')\n")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=repo, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

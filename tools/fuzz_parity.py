@@ -23,7 +23,7 @@ def note(kind, err, tol, desc):
     if not (err < tol):
         fails.append((kind, err, desc))
 while time.time() - t0 < budget:
-    k = rng.integers(0, 11)
+    k = rng.integers(0, 15)
     if k == 0:      # CAF
         F = int(rng.choice([2, 8, 16, 51, 64, 128]))
         N = int(rng.integers(max(2 * F, 600), 40000))
@@ -83,6 +83,43 @@ while time.time() - t0 < budget:
         n = int(rng.integers(28, 60000)); q = int(rng.choice([1, 2, 3, 4, 5, 8, 10]))
         x = scene.white_reference(n, int(rng.integers(1 << 30)))
         note("decimate_iir", rel(decimate_iir(x, q), O.decimate_iir(x, q)), 2e-5, ("dec", n, q))
+    elif k == 11:   # CAF variants: zero-pad branch, long decimation FIR, named window, complex128 surveillance
+        F = int(rng.choice([8, 16, 50])); N = int(rng.integers(2500, 20000)); R = int(rng.integers(1, 60))
+        ref, srv = scene.make_scene(N, 1e4, R, int(rng.integers(1 << 30)))
+        v = int(rng.integers(0, 4))
+        if v == 0:
+            n_in = int(rng.integers(N // 2, N)); a, b = ref[:n_in], srv[:n_in]
+            note("caf_pad", rel(fast_xambg(a, b, R, F, N), O.fast_xambg(a, b, R, F, N)), 2e-5, ("cafpad", N, n_in, R, F))
+        elif v == 1:
+            note("caf_longfilt", rel(fast_xambg(ref, srv, R, F, N, None, False), O.fast_xambg(ref, srv, R, F, N, None, False)), 2e-5, ("caflong", N, R, F))
+        elif v == 2:
+            w = ("kaiser", float(rng.choice([2.0, 5.0]))) if rng.random() < 0.5 else "hann"
+            note("caf_namedwin", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("cafwin", N, R, F, w))
+        else:
+            note("caf_c128", rel(fast_xambg(ref, srv.astype(np.complex128), R, F), O.fast_xambg(ref, srv.astype(np.complex128), R, F)), 2e-5, ("caf128", N, R, F))
+    elif k == 12:   # NLMS warm start
+        N = int(rng.integers(400, 4000)); L = int(rng.integers(1, 300)); mu = 0.05
+        ref, srv = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
+        t0_ = (rng.standard_normal(L + 10) + 1j * rng.standard_normal(L + 10)).astype(np.complex64) * 0.05
+        if N > L + 12:
+            g, gt = NLMS_filter(ref, srv, L, mu, 10, t0_, True); e, et = O.NLMS_filter(ref, srv, L, mu, 10, t0_, True)
+            note("nlms_warm", max(rel(g, e), rel(gt, et)), 1e-4, ("nlmswarm", N, L))
+    elif k == 13:   # block-phase frequency shift (complex128 result)
+        n = int(rng.integers(10, 50000)); fc = float(rng.uniform(-3e5, 3e5)); ph = float(rng.uniform(-6, 6))
+        x = scene.white_reference(n, int(rng.integers(1 << 30)))
+        g = frequency_shift(x, fc, 2.4e6, np.array([ph])); e = O.frequency_shift(x, fc, 2.4e6, np.array([ph]))
+        note("freqshift_block", rel(g, e) if g.dtype == e.dtype else 1.0, 2e-6, ("fsb", n, fc, ph))
+    elif k == 14:   # sharded stream == unsharded stream, random geometry
+        import torch
+        from passiveradar_amd.stream import HipBackend, StreamProcessor
+        C = int(rng.choice([4096, 6000, 8192])); nch = int(rng.integers(2, 9)); R = int(rng.integers(4, 40)); F = int(rng.choice([16, 32, 64]))
+        world = int(rng.integers(2, 5)); batch = int(rng.integers(1, 6))
+        a, b = scene.make_stream(nch, C, 2.6e5, R, int(rng.integers(1 << 30)))
+        be = HipBackend(2 * C, R, F, 2.6e5, batch=batch)
+        full = StreamProcessor(be).process(a, b).cpu().numpy()
+        parts = np.concatenate([StreamProcessor(be, r, world).process_local(a, b)[0].cpu().numpy() for r in range(world)])
+        exp = np.moveaxis(O.process_stream(a, b, 2 * C, R, F, 2.6e5), 2, 0)
+        note("stream", max(rel(parts, full), rel(full, exp)), 1e-4, ("stream", C, nch, R, F, world, batch))
     else:           # channel offset
         N = int(rng.integers(2000, 40000)); nd = int(rng.choice([1, 1, 2, 4])); nl = int(rng.integers(10, 3000)); sh = int(rng.integers(-nl // 2, nl // 2 + 1))
         a = scene.white_reference(N + 8000, int(rng.integers(1 << 30)))
