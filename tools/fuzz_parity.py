@@ -10,121 +10,136 @@ from passiveradar_amd.range_doppler_processing import fast_xambg
 from passiveradar_amd.signal_utils import decimate_iir, deinterleave_IQ, find_channel_offset, frequency_shift, front_end, resample, xcorr
 from passiveradar_amd.target_detection import CFAR_2D
 
+import threading
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 90.0
-rng = np.random.default_rng(seed)
+nthreads = int(sys.argv[3]) if len(sys.argv) > 3 else 1        # dask-style concurrent callers
 rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-30))
 worst, fails, ncase = {}, [], 0
+lock = threading.Lock()
 t0 = time.time()
 def note(kind, err, tol, desc):
     global ncase
-    ncase += 1
-    worst[kind] = max(worst.get(kind, 0.0), err)
-    if not (err < tol):
-        fails.append((kind, err, desc))
-while time.time() - t0 < budget:
-    k = rng.integers(0, 15)
-    if k == 0:      # CAF
-        F = int(rng.choice([2, 8, 16, 51, 64, 128]))
-        N = int(rng.integers(max(2 * F, 600), 40000))
-        R = int(rng.integers(1, min(300, N // 3)))
-        ref, srv = scene.make_scene(N, 1e4, R, int(rng.integers(1 << 30)))
-        win = rng.choice([None, "arr"])
-        w = None if win is None else np.kaiser(N, 3.0)
-        note("caf", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("caf", N, R, F, win))
-    elif k == 1:    # LS Toeplitz / direct
-        N = int(rng.integers(300, 30000)); L = int(rng.integers(1, min(200, N // 8))); peek = int(rng.integers(0, 12))
-        ref, srv = scene.make_scene(N, 1e4, max(L, 50), int(rng.integers(1 << 30)))
-        if rng.random() < 0.5:
-            got, gt = LS_Filter_Toeplitz(ref, srv, L, peek, True); exp, et = O.LS_Filter_Toeplitz(ref, srv, L, peek, True)
-            note("ls_toeplitz", max(rel(got, exp), rel(gt, et)), 1e-4, ("toep", N, L, peek))
-        else:
-            reg = float(rng.choice([0.0, 1.0, 10.0]))
-            got = LS_Filter(ref, srv, L, reg, peek); exp = O.LS_Filter(ref, srv, L, reg, peek)
-            note("ls_direct", rel(got, exp), 1e-4, ("direct", N, L, reg, peek))
-    elif k == 2:    # LS multiple (cached chain when N >= 20000)
-        N = int(rng.integers(2000, 60000)); L = int(rng.integers(2, 120))
-        fs = float(rng.choice([1e4, 2.4e5, 2.4e6]))
-        nb = int(rng.integers(1, 6)); bins = [float(b) for b in rng.integers(-3, 4, nb)]
-        ref, srv = scene.make_scene(N, fs, max(L, 50), int(rng.integers(1 << 30)))
-        note("ls_multiple", rel(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)), 1e-4, ("multi", N, L, fs, bins))
-    elif k == 3:    # NLMS
-        N = int(rng.integers(200, 6000)); L = int(rng.integers(1, 2030)); mu = float(rng.choice([0.01, 0.05, 0.2]))
-        ref, srv = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
-        note("nlms", rel(NLMS_filter(ref, srv, L, mu), c_oracle.nlms(ref, srv, L, mu)[0]) if N > L + 10 else 0.0, 1e-4, ("nlms", N, L, mu))
-    elif k == 4:    # xcorr
-        N = int(rng.integers(100, 50000)); nlead = int(rng.integers(0, 40)); nlag = int(rng.integers(1, 300))
-        a, b = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
-        note("xcorr", rel(xcorr(a, b, nlead, nlag), O.xcorr(a, b, nlead, nlag)), 2e-5, ("xcorr", N, nlead, nlag))
-    elif k == 6:    # big CAF: several lag blocks, long CPIs
-        F = int(rng.choice([4, 32, 100])); N = int(rng.integers(20000, 300000)); R = int(rng.integers(200, 1200))
-        ref, srv = scene.make_scene(N, 1e5, R, int(rng.integers(1 << 30)))
-        note("caf_big", rel(fast_xambg(ref, srv, R, F), c_oracle.fast_xambg(ref, srv, R, F)), 2e-5, ("cafbig", N, R, F))
-    elif k == 7:    # LS near the FFT-kernel limit (T - 1 <= 768) and long blocks
-        N = int(rng.integers(20000, 200000)); L = int(rng.choice([200, 500, 740, 758, 759, 760, 800]))
-        fs = 2.4e6; bins = [0.0, 1.0, -1.0][:int(rng.integers(1, 4))]
-        ref, srv = scene.make_scene(N, fs, 100, int(rng.integers(1 << 30)))
-        note("ls_long", rel(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)), 1e-4, ("lslong", N, L, bins))
-    elif k == 8:    # front end pieces
-        n = int(rng.integers(100, 30000))
-        dt = rng.choice(["int8", "uint8", "int16", "float32"])
-        raw = (rng.standard_normal(2 * n) * 30).astype(dt)
-        ok = np.array_equal(deinterleave_IQ(raw), O.deinterleave_IQ(raw))
-        x = O.deinterleave_IQ(raw)[:max(n // 2, 40)]
-        up, dn = int(rng.integers(1, 20)), int(rng.integers(1, 130))
-        e1 = rel(resample(x, up, dn), O.resample(x, up, dn))
-        fc = float(rng.uniform(-2e5, 2e5)); e2 = rel(frequency_shift(x, fc, 2.4e6, 0.3), O.frequency_shift(x, fc, 2.4e6, 0.3))
-        note("front_end", max(e1, e2, 0.0 if ok else 1.0), 2e-5, ("fe", n, dt, up, dn, fc))
-    elif k == 9:    # CFAR
-        H, W = int(rng.integers(20, 300)), int(rng.integers(20, 300)); fw = int(rng.integers(3, 19)); gw = int(rng.integers(0, fw - 1))
-        X = np.abs(rng.standard_normal((H, W))).astype(np.float32) + 0.1
-        note("cfar", rel(CFAR_2D(X, fw, gw), O.CFAR_2D(X, fw, gw)), 2e-5, ("cfar", H, W, fw, gw))
-    elif k == 10:   # zero-phase IIR decimator
-        n = int(rng.integers(28, 60000)); q = int(rng.choice([1, 2, 3, 4, 5, 8, 10]))
-        x = scene.white_reference(n, int(rng.integers(1 << 30)))
-        note("decimate_iir", rel(decimate_iir(x, q), O.decimate_iir(x, q)), 2e-5, ("dec", n, q))
-    elif k == 11:   # CAF variants: zero-pad branch, long decimation FIR, named window, complex128 surveillance
-        F = int(rng.choice([8, 16, 50])); N = int(rng.integers(2500, 20000)); R = int(rng.integers(1, 60))
-        ref, srv = scene.make_scene(N, 1e4, R, int(rng.integers(1 << 30)))
-        v = int(rng.integers(0, 4))
-        if v == 0:
-            n_in = int(rng.integers(N // 2, N)); a, b = ref[:n_in], srv[:n_in]
-            note("caf_pad", rel(fast_xambg(a, b, R, F, N), O.fast_xambg(a, b, R, F, N)), 2e-5, ("cafpad", N, n_in, R, F))
-        elif v == 1:
-            note("caf_longfilt", rel(fast_xambg(ref, srv, R, F, N, None, False), O.fast_xambg(ref, srv, R, F, N, None, False)), 2e-5, ("caflong", N, R, F))
-        elif v == 2:
-            w = ("kaiser", float(rng.choice([2.0, 5.0]))) if rng.random() < 0.5 else "hann"
-            note("caf_namedwin", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("cafwin", N, R, F, w))
-        else:
-            note("caf_c128", rel(fast_xambg(ref, srv.astype(np.complex128), R, F), O.fast_xambg(ref, srv.astype(np.complex128), R, F)), 2e-5, ("caf128", N, R, F))
-    elif k == 12:   # NLMS warm start
-        N = int(rng.integers(400, 4000)); L = int(rng.integers(1, 300)); mu = 0.05
-        ref, srv = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
-        t0_ = (rng.standard_normal(L + 10) + 1j * rng.standard_normal(L + 10)).astype(np.complex64) * 0.05
-        if N > L + 12:
-            g, gt = NLMS_filter(ref, srv, L, mu, 10, t0_, True); e, et = O.NLMS_filter(ref, srv, L, mu, 10, t0_, True)
-            note("nlms_warm", max(rel(g, e), rel(gt, et)), 1e-4, ("nlmswarm", N, L))
-    elif k == 13:   # block-phase frequency shift (complex128 result)
-        n = int(rng.integers(10, 50000)); fc = float(rng.uniform(-3e5, 3e5)); ph = float(rng.uniform(-6, 6))
-        x = scene.white_reference(n, int(rng.integers(1 << 30)))
-        g = frequency_shift(x, fc, 2.4e6, np.array([ph])); e = O.frequency_shift(x, fc, 2.4e6, np.array([ph]))
-        note("freqshift_block", rel(g, e) if g.dtype == e.dtype else 1.0, 2e-6, ("fsb", n, fc, ph))
-    elif k == 14:   # sharded stream == unsharded stream, random geometry
-        import torch
-        from passiveradar_amd.stream import HipBackend, StreamProcessor
-        C = int(rng.choice([4096, 6000, 8192])); nch = int(rng.integers(2, 9)); R = int(rng.integers(4, 40)); F = int(rng.choice([16, 32, 64]))
-        world = int(rng.integers(2, 5)); batch = int(rng.integers(1, 6))
-        a, b = scene.make_stream(nch, C, 2.6e5, R, int(rng.integers(1 << 30)))
-        be = HipBackend(2 * C, R, F, 2.6e5, batch=batch)
-        full = StreamProcessor(be).process(a, b).cpu().numpy()
-        parts = np.concatenate([StreamProcessor(be, r, world).process_local(a, b)[0].cpu().numpy() for r in range(world)])
-        exp = np.moveaxis(O.process_stream(a, b, 2 * C, R, F, 2.6e5), 2, 0)
-        note("stream", max(rel(parts, full), rel(full, exp)), 1e-4, ("stream", C, nch, R, F, world, batch))
-    else:           # channel offset
-        N = int(rng.integers(2000, 40000)); nd = int(rng.choice([1, 1, 2, 4])); nl = int(rng.integers(10, 3000)); sh = int(rng.integers(-nl // 2, nl // 2 + 1))
-        a = scene.white_reference(N + 8000, int(rng.integers(1 << 30)))
-        s1, s2 = a[4000:4000 + N], a[4000 - sh:4000 - sh + N]
-        note("chan_offset", 0.0 if find_channel_offset(s1, s2, nd, nl) == O.find_channel_offset(s1, s2, nd, nl) else 1.0, 0.5, ("off", N, nd, nl, sh))
+    with lock:
+        ncase += 1
+        worst[kind] = max(worst.get(kind, 0.0), err)
+        if not (err < tol):
+            fails.append((kind, err, desc))
+def worker(wseed):
+  rng = np.random.default_rng(wseed)
+  while time.time() - t0 < budget:
+      k = rng.integers(0, 15)
+      if k == 0:      # CAF
+          F = int(rng.choice([2, 8, 16, 51, 64, 128]))
+          N = int(rng.integers(max(2 * F, 600), 40000))
+          R = int(rng.integers(1, min(300, N // 3)))
+          ref, srv = scene.make_scene(N, 1e4, R, int(rng.integers(1 << 30)))
+          win = rng.choice([None, "arr"])
+          w = None if win is None else np.kaiser(N, 3.0)
+          note("caf", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("caf", N, R, F, win))
+      elif k == 1:    # LS Toeplitz / direct
+          N = int(rng.integers(300, 30000)); L = int(rng.integers(1, min(200, N // 8))); peek = int(rng.integers(0, 12))
+          ref, srv = scene.make_scene(N, 1e4, max(L, 50), int(rng.integers(1 << 30)))
+          if rng.random() < 0.5:
+              got, gt = LS_Filter_Toeplitz(ref, srv, L, peek, True); exp, et = O.LS_Filter_Toeplitz(ref, srv, L, peek, True)
+              note("ls_toeplitz", max(rel(got, exp), rel(gt, et)), 1e-4, ("toep", N, L, peek))
+          else:
+              reg = float(rng.choice([0.0, 1.0, 10.0]))
+              got = LS_Filter(ref, srv, L, reg, peek); exp = O.LS_Filter(ref, srv, L, reg, peek)
+              note("ls_direct", rel(got, exp), 1e-4, ("direct", N, L, reg, peek))
+      elif k == 2:    # LS multiple (cached chain when N >= 20000)
+          N = int(rng.integers(2000, 60000)); L = int(rng.integers(2, 120))
+          fs = float(rng.choice([1e4, 2.4e5, 2.4e6]))
+          nb = int(rng.integers(1, 6)); bins = [float(b) for b in rng.integers(-3, 4, nb)]
+          ref, srv = scene.make_scene(N, fs, max(L, 50), int(rng.integers(1 << 30)))
+          note("ls_multiple", rel(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)), 1e-4, ("multi", N, L, fs, bins))
+      elif k == 3:    # NLMS
+          N = int(rng.integers(200, 6000)); L = int(rng.integers(1, 2030)); mu = float(rng.choice([0.01, 0.05, 0.2]))
+          ref, srv = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
+          note("nlms", rel(NLMS_filter(ref, srv, L, mu), c_oracle.nlms(ref, srv, L, mu)[0]) if N > L + 10 else 0.0, 1e-4, ("nlms", N, L, mu))
+      elif k == 4:    # xcorr
+          N = int(rng.integers(100, 50000)); nlead = int(rng.integers(0, 40)); nlag = int(rng.integers(1, 300))
+          a, b = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
+          note("xcorr", rel(xcorr(a, b, nlead, nlag), O.xcorr(a, b, nlead, nlag)), 2e-5, ("xcorr", N, nlead, nlag))
+      elif k == 6:    # big CAF: several lag blocks, long CPIs
+          F = int(rng.choice([4, 32, 100])); N = int(rng.integers(20000, 300000)); R = int(rng.integers(200, 1200))
+          ref, srv = scene.make_scene(N, 1e5, R, int(rng.integers(1 << 30)))
+          note("caf_big", rel(fast_xambg(ref, srv, R, F), c_oracle.fast_xambg(ref, srv, R, F)), 2e-5, ("cafbig", N, R, F))
+      elif k == 7:    # LS near the FFT-kernel limit (T - 1 <= 768) and long blocks
+          N = int(rng.integers(20000, 200000)); L = int(rng.choice([200, 500, 740, 758, 759, 760, 800]))
+          fs = 2.4e6; bins = [0.0, 1.0, -1.0][:int(rng.integers(1, 4))]
+          ref, srv = scene.make_scene(N, fs, 100, int(rng.integers(1 << 30)))
+          note("ls_long", rel(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)), 1e-4, ("lslong", N, L, bins))
+      elif k == 8:    # front end pieces
+          n = int(rng.integers(100, 30000))
+          dt = rng.choice(["int8", "uint8", "int16", "float32"])
+          raw = (rng.standard_normal(2 * n) * 30).astype(dt)
+          ok = np.array_equal(deinterleave_IQ(raw), O.deinterleave_IQ(raw))
+          x = O.deinterleave_IQ(raw)[:max(n // 2, 40)]
+          up, dn = int(rng.integers(1, 20)), int(rng.integers(1, 130))
+          e1 = rel(resample(x, up, dn), O.resample(x, up, dn))
+          fc = float(rng.uniform(-2e5, 2e5)); e2 = rel(frequency_shift(x, fc, 2.4e6, 0.3), O.frequency_shift(x, fc, 2.4e6, 0.3))
+          note("front_end", max(e1, e2, 0.0 if ok else 1.0), 2e-5, ("fe", n, dt, up, dn, fc))
+      elif k == 9:    # CFAR
+          H, W = int(rng.integers(20, 300)), int(rng.integers(20, 300)); fw = int(rng.integers(3, 19)); gw = int(rng.integers(0, fw - 1))
+          X = np.abs(rng.standard_normal((H, W))).astype(np.float32) + 0.1
+          note("cfar", rel(CFAR_2D(X, fw, gw), O.CFAR_2D(X, fw, gw)), 2e-5, ("cfar", H, W, fw, gw))
+      elif k == 10:   # zero-phase IIR decimator
+          n = int(rng.integers(28, 60000)); q = int(rng.choice([1, 2, 3, 4, 5, 8, 10]))
+          x = scene.white_reference(n, int(rng.integers(1 << 30)))
+          note("decimate_iir", rel(decimate_iir(x, q), O.decimate_iir(x, q)), 2e-5, ("dec", n, q))
+      elif k == 11:   # CAF variants: zero-pad branch, long decimation FIR, named window, complex128 surveillance
+          F = int(rng.choice([8, 16, 50])); N = int(rng.integers(2500, 20000)); R = int(rng.integers(1, 60))
+          ref, srv = scene.make_scene(N, 1e4, R, int(rng.integers(1 << 30)))
+          v = int(rng.integers(0, 4))
+          if v == 0:
+              n_in = int(rng.integers(N // 2, N)); a, b = ref[:n_in], srv[:n_in]
+              note("caf_pad", rel(fast_xambg(a, b, R, F, N), O.fast_xambg(a, b, R, F, N)), 2e-5, ("cafpad", N, n_in, R, F))
+          elif v == 1:
+              note("caf_longfilt", rel(fast_xambg(ref, srv, R, F, N, None, False), O.fast_xambg(ref, srv, R, F, N, None, False)), 2e-5, ("caflong", N, R, F))
+          elif v == 2:
+              w = ("kaiser", float(rng.choice([2.0, 5.0]))) if rng.random() < 0.5 else "hann"
+              note("caf_namedwin", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("cafwin", N, R, F, w))
+          else:
+              note("caf_c128", rel(fast_xambg(ref, srv.astype(np.complex128), R, F), O.fast_xambg(ref, srv.astype(np.complex128), R, F)), 2e-5, ("caf128", N, R, F))
+      elif k == 12:   # NLMS warm start
+          N = int(rng.integers(400, 4000)); L = int(rng.integers(1, 300)); mu = 0.05
+          ref, srv = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
+          t0_ = (rng.standard_normal(L + 10) + 1j * rng.standard_normal(L + 10)).astype(np.complex64) * 0.05
+          if N > L + 12:
+              g, gt = NLMS_filter(ref, srv, L, mu, 10, t0_, True); e, et = O.NLMS_filter(ref, srv, L, mu, 10, t0_, True)
+              note("nlms_warm", max(rel(g, e), rel(gt, et)), 1e-4, ("nlmswarm", N, L))
+      elif k == 13:   # block-phase frequency shift (complex128 result)
+          n = int(rng.integers(10, 50000)); fc = float(rng.uniform(-3e5, 3e5)); ph = float(rng.uniform(-6, 6))
+          x = scene.white_reference(n, int(rng.integers(1 << 30)))
+          g = frequency_shift(x, fc, 2.4e6, np.array([ph])); e = O.frequency_shift(x, fc, 2.4e6, np.array([ph]))
+          note("freqshift_block", rel(g, e) if g.dtype == e.dtype else 1.0, 2e-6, ("fsb", n, fc, ph))
+      elif k == 14:   # sharded stream == unsharded stream, random geometry
+          import torch
+          from passiveradar_amd.stream import HipBackend, StreamProcessor
+          C = int(rng.choice([4096, 6000, 8192])); nch = int(rng.integers(2, 9)); R = int(rng.integers(4, 40)); F = int(rng.choice([16, 32, 64]))
+          world = int(rng.integers(2, 5)); batch = int(rng.integers(1, 6))
+          a, b = scene.make_stream(nch, C, 2.6e5, R, int(rng.integers(1 << 30)))
+          be = HipBackend(2 * C, R, F, 2.6e5, batch=batch)
+          full = StreamProcessor(be).process(a, b).cpu().numpy()
+          parts = np.concatenate([StreamProcessor(be, r, world).process_local(a, b)[0].cpu().numpy() for r in range(world)])
+          exp = np.moveaxis(O.process_stream(a, b, 2 * C, R, F, 2.6e5), 2, 0)
+          note("stream", max(rel(parts, full), rel(full, exp)), 1e-4, ("stream", C, nch, R, F, world, batch))
+      else:           # channel offset
+          N = int(rng.integers(2000, 40000)); nd = int(rng.choice([1, 1, 2, 4])); nl = int(rng.integers(10, 3000)); sh = int(rng.integers(-nl // 2, nl // 2 + 1))
+          a = scene.white_reference(N + 8000, int(rng.integers(1 << 30)))
+          s1, s2 = a[4000:4000 + N], a[4000 - sh:4000 - sh + N]
+          note("chan_offset", 0.0 if find_channel_offset(s1, s2, nd, nl) == O.find_channel_offset(s1, s2, nd, nl) else 1.0, 0.5, ("off", N, nd, nl, sh))
+def guarded(wseed):
+    try:
+        worker(wseed)
+    except Exception as e:          # a crash in one thread is a failure, not a silent exit
+        import traceback
+        with lock:
+            fails.append(("exception", 1.0, traceback.format_exc()[-600:]))
+threads = [threading.Thread(target=guarded, args=(seed * 1000 + i,)) for i in range(nthreads)]
+[t.start() for t in threads]
+[t.join() for t in threads]
 print(f"{ncase} random cases in {time.time() - t0:.0f} s; worst relative error per kind:", {k: f"{v:.1e}" for k, v in worst.items()})
 print("FAILURES:", fails if fails else "none")
 sys.exit(1 if fails else 0)
