@@ -381,3 +381,36 @@ def test_library_first_then_torch_in_a_fresh_process():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=repo, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("nstreams,L", [(5, 24), (9, 90), (1030, 24), (2100, 24), (3100, 24)])
+def test_nlms_many_streams(nstreams, L):
+    """batched NLMS through the C ABI: independent streams at a stride, one wavefront each, 4 / 8 / 12 wavefronts
+    per workgroup depending on the stream count (1030 -> two per SIMD, 3100 -> three), taps in and out per stream"""
+    import torch
+    from oracle import c_oracle
+    from passiveradar_amd import engine
+    n, stride = 500, 512
+    base_ref, base_srv = scene.make_scene(nstreams * 7 + n, 1e4, 50, 31 + nstreams)
+    ref = np.zeros((nstreams, stride), np.complex64)
+    srv = np.zeros((nstreams, stride), np.complex64)
+    tin = np.zeros((nstreams, L + 10), np.complex64)
+    rng = np.random.default_rng(nstreams)
+    for s in range(nstreams):
+        ref[s, :n] = base_ref[7 * s:7 * s + n]
+        srv[s, :n] = base_srv[7 * s:7 * s + n]
+    warm = nstreams <= 9
+    if warm:
+        tin[:] = (rng.standard_normal(tin.shape) + 1j * rng.standard_normal(tin.shape)).astype(np.complex64) * 0.05
+    dr, ds = torch.from_numpy(ref).cuda(), torch.from_numpy(srv).cuda()
+    do = torch.full((nstreams, stride), 7.0 + 0j, dtype=torch.complex64, device="cuda")
+    dti = torch.from_numpy(tin).cuda()
+    dto = torch.empty_like(dti)
+    engine.nlms_execute(dr, ds, do, n, L, 0.05, 10, dti if warm else None, dto, nstreams, stride, stride)
+    torch.cuda.synchronize()
+    out, taps = do.cpu().numpy(), dto.cpu().numpy()
+    assert np.all(out[:, n:] == 7.0)                                   # nothing written past a stream's n samples
+    check = range(nstreams) if nstreams <= 9 else list(range(0, nstreams, 97)) + [nstreams - 1, nstreams - 2, 1023 % nstreams, 1024 % nstreams]
+    for s in check:
+        e, et = c_oracle.nlms(ref[s, :n], srv[s, :n], L, 0.05, 10, tin[s] if warm else None)
+        assert rel_err(out[s, :n], e) < TOL and rel_err(taps[s], et) < TOL, s

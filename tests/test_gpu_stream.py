@@ -163,3 +163,24 @@ def test_cfg2_pipeline_against_reference_output():
     Xo = O.fast_xambg_libcalls(np.concatenate((pad, a, pad))[C:C + n].astype(np.complex64),
                                np.concatenate((pad, exact, pad))[C:C + n].astype(np.complex64), R, F, w)[:, :, 0]
     assert rel_err(X, Xo) < 1e-5
+
+
+def test_stream_with_nlms_canceller():
+    """HipBackend(clutter='nlms'): every hop chunk is an independent NLMS stream (batched launch), frames from the
+    cleaned stream -- against per-chunk NLMS (C twin of the oracle) + the oracle's CAF on the overlapped frames"""
+    import torch
+    from oracle import c_oracle, np_oracle as O
+    from passiveradar_amd import scene
+    from passiveradar_amd.stream import HipBackend, StreamProcessor
+    C, R, F, nch, fs = 4096, 20, 32, 7, 2.6e5
+    a, b = scene.make_stream(nch, C, fs, R, 424242)
+    be = HipBackend(2 * C, R, F, fs, clutter="nlms", batch=4, nlms_mu=0.05)
+    got = StreamProcessor(be).process(a, b)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    cleaned = np.concatenate([c_oracle.nlms(a[i * C:(i + 1) * C], b[i * C:(i + 1) * C], R, 0.05, 10)[0] for i in range(nch)])
+    from scipy.signal import get_window
+    w = get_window(("kaiser", 5.0), 2 * C)
+    rf, sf = O.overlap_frames(a, C, C // 2), O.overlap_frames(cleaned, C, C // 2)
+    exp = np.stack([O.fast_xambg(x, y, R, F, 2 * C, w)[:, :, 0] for x, y in zip(rf, sf)])
+    assert got.shape == exp.shape and rel_err(got, exp) < 1e-4
