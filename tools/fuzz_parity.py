@@ -117,7 +117,7 @@ def worker(wseed):
       elif k == 14:   # sharded stream == unsharded stream, random geometry
           import torch
           from passiveradar_amd.stream import HipBackend, StreamProcessor
-          C = int(rng.choice([4096, 6000, 8192])); nch = int(rng.integers(2, 9)); R = int(rng.integers(4, 40)); F = int(rng.choice([16, 32, 64]))
+          C = int(rng.choice([4096, 6000, 8192, 24000, 30011])); nch = int(rng.integers(2, 9 if C < 20000 else 5)); R = int(rng.integers(4, 40)); F = int(rng.choice([16, 32, 64]))
           world = int(rng.integers(2, 5)); batch = int(rng.integers(1, 6))
           a, b = scene.make_stream(nch, C, 2.6e5, R, int(rng.integers(1 << 30)))
           be = HipBackend(2 * C, R, F, 2.6e5, batch=batch)
