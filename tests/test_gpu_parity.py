@@ -414,3 +414,18 @@ def test_nlms_many_streams(nstreams, L):
     for s in check:
         e, et = c_oracle.nlms(ref[s, :n], srv[s, :n], L, 0.05, 10, tin[s] if warm else None)
         assert rel_err(out[s, :n], e) < TOL and rel_err(taps[s], et) < TOL, s
+
+
+def test_argument_ranges_the_reference_accepts():
+    """found by tools/fuzz_parity.py: lags beyond the signal length (zero sums), equal up/down factors (a copy),
+    and a decimation ratio whose staged span needs fewer outputs per workgroup to fit LDS"""
+    from passiveradar_amd.signal_utils import resample, xcorr
+    a, b = scene.make_scene(150, 1e4, 20, 8)
+    assert rel_err(xcorr(a, b, 30, 260), O.xcorr(a, b, 30, 260)) < TIGHT
+    z = xcorr(a, b, 0, 400)
+    assert z.shape == (401,) and not z[151:].any()
+    x = scene.white_reference(4000, 5)
+    y = resample(x, 7, 7)
+    assert y is not x and np.array_equal(y, x)
+    for up, dn in ((1, 101), (3, 128), (19, 2)):
+        assert rel_err(resample(x, up, dn), O.resample(x, up, dn)) < TIGHT, (up, dn)
