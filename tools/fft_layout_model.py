@@ -81,3 +81,49 @@ if __name__ == "__main__":
         gcor = inverse(np.conj(forward(u, r)) * forward(v, r), r)
         ref = np.array([np.vdot(u[:B], v[l:l + B]) for l in range(R + 1)])
         print("   corr", np.abs(gcor[:R + 1] - ref).max())
+
+
+# ---- the quad (radix-4 across four lanes) stage as fft_wave.h issues it -------------------------------------
+# Each butterfly r = s*c + c_partner with a per-lane sign s is ONE v_fmac_f32_dpp, d += dpp(d) * (-s), when it is
+# written on the sign-scaled value: the partner's sign is the opposite of one's own.  The scaling sg = sA*sB is
+# folded into the twiddle table in front of the stage (forward) or into the caller's spectrum (inverse).
+def quad_forward_fused(c):
+    """c[lane]: values after the W_64^(j m') twiddle for one register, 64 lanes; returns lane j' <- X[bitrev2(j')]"""
+    lanes = np.arange(64)
+    j = lanes & 3
+    sA = np.where(j < 2, 1.0, -1.0)
+    sB = np.where(j & 1, -1.0, 1.0)
+    u = (sA * sB) * c                          # folded into TW2S
+    u = u - sA * u[lanes ^ 2]                  # v_fmac_f32_dpp quad_perm:[2,3,0,1]
+    u = np.where(j == 3, -1j * u, u)           # lane 3 carries the -i twiddle
+    u = u - sB * u[lanes ^ 1]                  # v_fmac_f32_dpp quad_perm:[1,0,3,2]
+    return u
+
+
+def quad_inverse_fused(y):
+    lanes = np.arange(64)
+    j = lanes & 3
+    sA = np.where(j < 2, 1.0, -1.0)
+    sB = np.where(j & 1, -1.0, 1.0)
+    p = (sA * sB) * y                          # PRESCALED: folded into the filter spectrum by the caller
+    p = p - sB * p[lanes ^ 1]
+    p = np.where(j == 3, 1j * p, p)
+    p = p - sA * p[lanes ^ 2]
+    return p
+
+
+def _check_quad():
+    rng = np.random.default_rng(1)
+    c = rng.standard_normal(64) + 1j * rng.standard_normal(64)
+    lanes = np.arange(64)
+    base, j = lanes & ~3, lanes & 3
+    bitrev2 = np.array([0, 2, 1, 3])
+    want = np.array([sum(c[base[l] + jj] * np.exp(-2j * np.pi * jj * bitrev2[j[l]] / 4) for jj in range(4)) for l in lanes])
+    got = quad_forward_fused(c)
+    back = quad_inverse_fused(got) / 4
+    print("quad stage, fused-DPP form: forward vs 4-point DFT (bit-reversed lanes)", np.abs(got - want).max(),
+          " inverse(forward) vs input", np.abs(back - c).max())
+
+
+if __name__ == "__main__":
+    _check_quad()
