@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Build-container only (needs /root/reference): randomised check that the oracle restates the REFERENCE itself,
+function by function, on shapes the fixed goldens do not hold.  The GPU path is compared with the oracle, so this is
+the other half of the parity chain.      python tools/fuzz_oracle_vs_reference.py [seed] [seconds]"""
+import os, sys, time, warnings
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, "/root/reference"); sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "oracle"))
+warnings.filterwarnings("ignore")
+import numpy as np
+np.float = float; np.int = int                      # target_detection.py uses the removed aliases
+from passiveRadar import range_doppler_processing as ref_rd, clutter_removal as ref_cr, signal_utils as ref_su
+from passiveRadar import target_detection as ref_td
+from oracle import np_oracle as O
+from oracle.gen_golden import no_root_finding
+from passiveradar_amd import scene
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+rng = np.random.default_rng(seed)
+rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-30))
+worst, fails, n = {}, [], 0
+def note(kind, err, tol, desc):
+    global n
+    n += 1
+    worst[kind] = max(worst.get(kind, 0.0), err)
+    if not (err < tol):
+        fails.append((kind, err, desc))
+t0 = time.time()
+with no_root_finding():
+    while time.time() - t0 < budget:
+        k = int(rng.integers(0, 9))
+        if k == 0:
+            F = int(rng.choice([2, 7, 16, 33, 64])); N = int(rng.integers(max(3 * F, 200), 12000)); R = int(rng.integers(1, min(40, N // 4)))
+            a, b = scene.make_scene(N, 1e4, R, int(rng.integers(1 << 30)))
+            v = int(rng.integers(0, 4))
+            if v == 0:
+                note("caf", rel(O.fast_xambg(a, b, R, F), ref_rd.fast_xambg(a, b, R, F)), 2e-6, (N, R, F))
+            elif v == 1:
+                w = np.kaiser(N, 4.0); note("caf_win", rel(O.fast_xambg(a, b, R, F, N, w), ref_rd.fast_xambg(a, b, R, F, N, w)), 2e-6, (N, R, F))
+            elif v == 2:
+                m = int(rng.integers(N // 2, N)); note("caf_pad", rel(O.fast_xambg(a[:m], b[:m], R, F, N), ref_rd.fast_xambg(a[:m], b[:m], R, F, N)), 2e-6, (N, m, R, F))
+            else:
+                note("caf_longfilt", rel(O.fast_xambg(a, b, R, F, N, None, False), ref_rd.fast_xambg(a, b, R, F, N, None, False)), 2e-6, (N, R, F))
+        elif k == 1:
+            N = int(rng.integers(200, 8000)); L = int(rng.integers(1, min(60, N // 8))); pk = int(rng.integers(0, 12))
+            a, b = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
+            g, gt = O.LS_Filter_Toeplitz(a, b, L, pk, True); e, et = ref_cr.LS_Filter_Toeplitz(a, b, L, pk, True)
+            note("ls_toeplitz", max(rel(g, e), rel(gt, et)), 2e-5, (N, L, pk))
+        elif k == 2:
+            N = int(rng.integers(500, 8000)); L = int(rng.integers(2, 40)); fs = float(rng.choice([1e4, 2.4e5, 2.4e6]))
+            bins = [float(x) for x in rng.integers(-3, 4, int(rng.integers(1, 5)))]
+            a, b = scene.make_scene(N, fs, 50, int(rng.integers(1 << 30)))
+            note("ls_multiple", rel(O.LS_Filter_Multiple(a, b, L, fs, bins), ref_cr.LS_Filter_Multiple(a, b, L, fs, bins)), 2e-5, (N, L, fs, bins))
+        elif k == 3:
+            N = int(rng.integers(200, 3000)); L = int(rng.integers(1, min(40, N // 8))); reg = float(rng.choice([0.0, 1.0, 5.0])); pk = int(rng.integers(0, 12))
+            a, b = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
+            note("ls_direct", rel(O.LS_Filter(a, b, L, reg, pk), ref_cr.LS_Filter(a, b, L, reg, pk)), 2e-3, (N, L, reg, pk))   # reference: complex64 normal equations
+        elif k == 4:
+            N = int(rng.integers(60, 700)); L = int(rng.integers(1, 40)); mu = float(rng.choice([0.01, 0.1]))
+            a, b = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
+            if N > L + 12:
+                g, gt = O.NLMS_filter(a, b, L, mu, 10, None, True); e, et = ref_cr.NLMS_filter(a, b, L, mu, 10, None, True)
+                note("nlms", max(rel(g, e), rel(gt, et)), 2e-5, (N, L, mu))
+        elif k == 5:
+            N = int(rng.integers(50, 5000)); nlead, nlag = int(rng.integers(0, 30)), int(rng.integers(1, 120))
+            a, b = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
+            note("xcorr", rel(O.xcorr(a, b, nlead, nlag), ref_su.xcorr(a, b, nlead, nlag)), 5e-6, (N, nlead, nlag))
+            fc = float(rng.uniform(-3e5, 3e5))
+            note("freq_shift", rel(O.frequency_shift(a, fc, 2.4e6, 0.7), ref_su.frequency_shift(a, fc, 2.4e6, 0.7)), 1e-6, (N, fc))
+        elif k == 6:
+            nn = int(rng.integers(40, 6000)); up, dn = int(rng.integers(1, 20)), int(rng.integers(1, 130))
+            raw = (rng.standard_normal(2 * nn) * 40).astype(rng.choice(["int8", "int16", "float32"]))
+            ok = np.array_equal(O.deinterleave_IQ(raw), ref_su.deinterleave_IQ(raw))
+            x = ref_su.deinterleave_IQ(raw)
+            note("front_end", max(rel(O.resample(x, up, dn), ref_su.resample(x, up, dn)), 0.0 if ok else 1.0), 2e-5, (nn, up, dn))
+        elif k == 7:
+            H, W = int(rng.integers(20, 120)), int(rng.integers(20, 120)); fw = int(rng.integers(3, 19)); gw = int(rng.integers(0, fw - 1))
+            X = np.abs(rng.standard_normal((H, W))) + 0.1
+            note("cfar", rel(O.CFAR_2D(X, fw, gw), ref_td.CFAR_2D(X, fw, gw)), 1e-10, (H, W, fw, gw))
+        else:
+            N = int(rng.integers(500, 20000)); nd = int(rng.choice([1, 2, 4])); nl = int(rng.integers(5, 1500)); sh = int(rng.integers(-nl // 2, nl // 2 + 1))
+            base = scene.white_reference(N + 4000, int(rng.integers(1 << 30)))
+            s1, s2 = base[2000:2000 + N], base[2000 - sh:2000 - sh + N]
+            note("chan_offset", 0.0 if O.find_channel_offset(s1, s2, nd, nl) == ref_su.find_channel_offset(s1, s2, nd, nl) else 1.0, 0.5, (N, nd, nl, sh))
+print(f"{n} random cases in {time.time() - t0:.0f} s; worst oracle-vs-reference error per kind:", {k: f"{v:.1e}" for k, v in worst.items()})
+print("FAILURES:", fails if fails else "none")
