@@ -63,3 +63,18 @@ def test_product_does_not_import_the_oracle():
                 src = open(os.path.join(root, fn), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
                 assert "np_oracle" not in src and "liboracle" not in src, fn
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/prcore.h must stay a C header (the boundary a cgo / JNI / ctypes binding consumes): C99 and C++11"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "include/prcore.h"\nint main(void) { prc_caf_desc d; prc_ls_desc l; prc_iir_desc i; prc_frontend_desc f;\n'
+                   '  (void)d; (void)l; (void)i; (void)f; return prc_version() > 0 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", repo, str(src)])
+    if shutil.which("g++"):
+        subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", repo, "-x", "c++", str(src)])
