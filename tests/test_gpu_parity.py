@@ -429,3 +429,36 @@ def test_argument_ranges_the_reference_accepts():
     assert y is not x and np.array_equal(y, x)
     for up, dn in ((1, 101), (3, 128), (19, 2)):
         assert rel_err(resample(x, up, dn), O.resample(x, up, dn)) < TIGHT, (up, dn)
+
+
+def test_plain_c_host_of_the_abi(tmp_path):
+    """examples/c_host.c: a C99 program that drives libprcore.so directly (no Python, no torch in that process) must
+    see the same cross-ambiguity surface as the Python drop-in on the same synthetic echo"""
+    import shutil
+    import subprocess
+    from passiveradar_amd.range_doppler_processing import fast_xambg
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", os.path.join(repo, "include"), os.path.join(repo, "examples", "c_host.c"),
+                           "-L", os.path.join(repo, "passiveradar_amd"), "-lprcore", "-lm",
+                           "-Wl,-rpath," + os.path.join(repo, "passiveradar_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    tok = r.stdout.split()
+    row, col, power, checksum = int(tok[2]), int(tok[4]), float(tok[6]), float(tok[8])
+    n, R, F = 8192, 20, 32
+    s = np.uint32(12345)
+    v = np.empty(2 * n, np.float32)
+    state = 12345
+    for i in range(2 * n):
+        state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
+        v[i] = np.float32((state >> 8) / 8388608.0 - 1.0)
+    ref = v.view(np.complex64)
+    i = np.arange(n)
+    srv = (ref[(i - 7) % n].astype(np.complex128) * np.exp(2j * np.pi * 5.0 * i / n)).astype(np.complex64)
+    X = fast_xambg(ref, srv, R, F)[:, :, 0]
+    P = np.abs(X.astype(np.complex128)) ** 2
+    assert (row, col) == tuple(int(t) for t in np.unravel_index(P.argmax(), P.shape)) == (F // 2 - 5, R - 7)
+    assert abs(power - P.max()) / P.max() < 1e-4 and abs(checksum - P.sum()) / P.sum() < 1e-4
