@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build-container only (needs /root/reference): randomised check that the oracle restates the REFERENCE itself,
 function by function, on shapes the fixed goldens do not hold.  The GPU path is compared with the oracle, so this is
-the other half of the parity chain.      python tools/fuzz_oracle_vs_reference.py [seed] [seconds]"""
+the other half of the parity chain.      python tests/fuzz_oracle_vs_reference.py [seed] [seconds]"""
 import os, sys, time, warnings
 sys.dont_write_bytecode = True
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

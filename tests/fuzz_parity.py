@@ -2,7 +2,7 @@
 kernels switch on (FFT vs direct CAF, lag blocking, cached vs per-bin LS chain, NLMS taps-per-lane buckets)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+sys.path.insert(0, "."); sys.path.insert(0, "tests")   # run from the repo root: python tests/fuzz_parity.py [seed] [seconds] [threads]
 from oracle import np_oracle as O, c_oracle
 from passiveradar_amd import scene
 from passiveradar_amd.clutter_removal import LS_Filter, LS_Filter_Multiple, LS_Filter_Toeplitz, NLMS_filter

@@ -417,7 +417,7 @@ def test_nlms_many_streams(nstreams, L):
 
 
 def test_argument_ranges_the_reference_accepts():
-    """found by tools/fuzz_parity.py: lags beyond the signal length (zero sums), equal up/down factors (a copy),
+    """found by tests/fuzz_parity.py: lags beyond the signal length (zero sums), equal up/down factors (a copy),
     and a decimation ratio whose staged span needs fewer outputs per workgroup to fit LDS"""
     from passiveradar_amd.signal_utils import resample, xcorr
     a, b = scene.make_scene(150, 1e4, 20, 8)

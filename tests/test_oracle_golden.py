@@ -203,24 +203,22 @@ def test_python_sosfilt_loop_matches_c_twin():
 
 
 def test_cfg2_pipeline_full_size():
-    """BASELINE config 2 end to end at full size against the reference's own output: the library-call form of
-    the oracle (float32 SciPy correlate, like the reference) reproduces it; the closed form (float64 sums)
-    shows how much of the map is the reference's own float32 noise -- 2.3e-4 of the peak, all of it on the
-    cancelled direct-path ridge at zero Doppler."""
-    import scipy.signal as sg
+    """BASELINE config 2 at full size against the reference's own output (one of the three 1.2 M-sample hop chunks,
+    to keep the CPU suite short): the library-call form of the oracle (float32 SciPy correlate, like the reference)
+    reproduces the cleaned stream; the closed form (float64 sums) shows how much of it is the reference's own
+    float32 noise -- 2e-5 of the stream, which becomes 2.3e-4 of the map's peak on the cancelled direct-path ridge
+    (tests/test_gpu_stream.py::test_cfg2_pipeline_against_reference_output holds the map numbers)."""
     g = load_golden("pipeline_cfg2")
-    n, R, F, fs = int(g["N"]), int(g["R"]), int(g["F"]), float(g["fs"])
+    n, R, fs = int(g["N"]), int(g["R"]), float(g["fs"])
     C = n // 2
     a, s = scene.make_stream(3, C, fs, R, int(g["seed"]))
     bins = [0, 1, -1, 2, -2]
-    lib = np.concatenate([O.LS_Filter_Multiple_libcalls(a[i * C:(i + 1) * C], s[i * C:(i + 1) * C], R, fs, bins)
-                          for i in range(3)])
-    assert rel_err(lib[::101], g["cleaned_sub"]) < 1e-6
-    exact = np.concatenate([O.LS_Filter_Multiple(a[i * C:(i + 1) * C], s[i * C:(i + 1) * C], R, fs, bins)
-                            for i in range(3)])
-    assert 5e-6 < rel_err(exact[::101], g["cleaned_sub"]) < 1e-4          # the reference's float32 accumulation
-    w = sg.get_window(("kaiser", 5.0), n)
-    pad = np.zeros(n // 4)
-    ap = np.concatenate((pad, a, pad))[C:C + n].astype(np.complex64)
-    X = O.fast_xambg_libcalls(ap, np.concatenate((pad, lib, pad))[C:C + n].astype(np.complex64), R, F, w)[:, :, 0]
-    assert rel_err(X, g["out"]) < 2e-6
+    i = 1
+    idx = np.arange(0, 3 * C, 101)
+    sel = idx[(idx >= i * C) & (idx < (i + 1) * C)]
+    want = g["cleaned_sub"][sel // 101]
+    scale = np.abs(g["cleaned_sub"]).max()                            # same normalisation as the whole-stream figure
+    lib = O.LS_Filter_Multiple_libcalls(a[i * C:(i + 1) * C], s[i * C:(i + 1) * C], R, fs, bins)
+    assert np.abs(lib[sel - i * C] - want).max() / scale < 1e-6
+    exact = O.LS_Filter_Multiple(a[i * C:(i + 1) * C], s[i * C:(i + 1) * C], R, fs, bins)
+    assert 2e-6 < np.abs(exact[sel - i * C] - want).max() / scale < 1e-4   # the reference's float32 accumulation
