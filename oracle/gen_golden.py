@@ -301,6 +301,19 @@ def big_cases():
              peak=mag.max())
 
 
+def ls_cfg1_case():
+    """BASELINE config 1 (the reference's own CPU-runnable case): one 131 072-sample hop chunk of the 262 184.87 Hz
+    IF stream through LS_Filter_Multiple with 256 range cells (T = 266) and the five Doppler bins of main.py:169-176."""
+    print("config-1 LS chunk (LS_Filter_Multiple, T=266, 5 bins)")
+    n, R, fs = 131072, 256, 262184.87
+    a, s = scene.make_scene(n, fs, R, scene.scene_seed(11))
+    t0 = time.time()
+    out = ref_cr.LS_Filter_Multiple(a, s, R, fs, [0, 1, -1, 2, -2])
+    print(f"  {time.time() - t0:.1f}s")
+    save("ls_cfg1", seed=scene.scene_seed(11), N=n, R=R, fs=fs, out_sub=out[::7].astype(np.complex64),
+         head=out[:600].astype(np.complex64), tail=out[-600:].astype(np.complex64))
+
+
 def pipeline_cfg2_case():
     """BASELINE config 2 end to end, from the reference's own functions: three 1.2 M-sample hop chunks through
     LS_Filter_Multiple (5 Doppler bins, T=266) and the middle overlapped frame (main.py:169-194 geometry)
@@ -348,5 +361,6 @@ if __name__ == "__main__":
         frontend_case()
         cfar_case()
         offset_case()
+        ls_cfg1_case()
     if args.big or args.only_big:
         big_cases()

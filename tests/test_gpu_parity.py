@@ -462,3 +462,15 @@ def test_plain_c_host_of_the_abi(tmp_path):
     P = np.abs(X.astype(np.complex128)) ** 2
     assert (row, col) == tuple(int(t) for t in np.unravel_index(P.argmax(), P.shape)) == (F // 2 - 5, R - 7)
     assert abs(power - P.max()) / P.max() < 1e-4 and abs(checksum - P.sum()) / P.sum() < 1e-4
+
+
+def test_ls_cfg1_chunk_golden():
+    """config 1's LS stage at full chunk size (cached five-bin chain, T = 266) against the reference's own output"""
+    from passiveradar_amd.clutter_removal import LS_Filter_Multiple
+    g = load_golden("ls_cfg1")
+    n, R, fs = int(g["N"]), int(g["R"]), float(g["fs"])
+    a, s = scene.make_scene(n, fs, R, int(g["seed"]))
+    out = LS_Filter_Multiple(a, s, R, fs, [0, 1, -1, 2, -2])
+    scale = np.abs(g["head"]).max()
+    assert np.abs(out[::7] - g["out_sub"]).max() / scale < 1e-5
+    assert np.abs(out[:600] - g["head"]).max() / scale < 1e-5 and np.abs(out[-600:] - g["tail"]).max() / scale < 1e-5

@@ -222,3 +222,14 @@ def test_cfg2_pipeline_full_size():
     assert np.abs(lib[sel - i * C] - want).max() / scale < 1e-6
     exact = O.LS_Filter_Multiple(a[i * C:(i + 1) * C], s[i * C:(i + 1) * C], R, fs, bins)
     assert 2e-6 < np.abs(exact[sel - i * C] - want).max() / scale < 1e-4   # the reference's float32 accumulation
+
+
+def test_ls_cfg1_chunk():
+    """config 1's LS stage at full chunk size (131 072 samples, T = 266, five bins) against the reference's output"""
+    g = load_golden("ls_cfg1")
+    n, R, fs = int(g["N"]), int(g["R"]), float(g["fs"])
+    a, s = scene.make_scene(n, fs, R, int(g["seed"]))
+    out = O.LS_Filter_Multiple(a, s, R, fs, [0, 1, -1, 2, -2])
+    scale = np.abs(g["head"]).max()
+    assert np.abs(out[::7] - g["out_sub"]).max() / scale < 1e-5
+    assert np.abs(out[:600] - g["head"]).max() / scale < 1e-5 and np.abs(out[-600:] - g["tail"]).max() / scale < 1e-5
