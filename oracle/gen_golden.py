@@ -314,6 +314,27 @@ def ls_cfg1_case():
          head=out[:600].astype(np.complex64), tail=out[-600:].astype(np.complex64))
 
 
+def pipeline_cfg1_case():
+    """BASELINE config 1 end to end (the reference's own CPU-runnable case, PRconfig.yaml with a 1 s CPI): three
+    131 072-sample hop chunks through LS_Filter_Multiple, the middle overlapped frame through fast_xambg
+    (256 range x 256 Doppler, Kaiser(5) window), main.py:169-194 geometry."""
+    print("config-1 pipeline frame (LS x5 + CAF)")
+    n, R, F, fs = 262144, 256, 256, 262184.87
+    C = n // 2
+    a, s = scene.make_stream(3, C, fs, R, scene.scene_seed(12))
+    cleaned = np.concatenate([
+        ref_cr.LS_Filter_Multiple(a[i * C:(i + 1) * C], s[i * C:(i + 1) * C], R, fs, [0, 1, -1, 2, -2])
+        for i in range(3)])
+    pad = np.zeros(n // 4)
+    ap = np.concatenate((pad, a, pad))
+    sp = np.concatenate((pad, cleaned, pad))
+    w = signal.get_window(("kaiser", 5.0), n)
+    with no_root_finding():
+        out = ref_rd.fast_xambg(ap[C:C + n], sp[C:C + n], R, F, n, w)
+    save("pipeline_cfg1", seed=scene.scene_seed(12), N=n, R=R, F=F, fs=fs, frame_index=1,
+         out=out[:, :, 0].astype(np.complex64))
+
+
 def pipeline_cfg2_case():
     """BASELINE config 2 end to end, from the reference's own functions: three 1.2 M-sample hop chunks through
     LS_Filter_Multiple (5 Doppler bins, T=266) and the middle overlapped frame (main.py:169-194 geometry)

@@ -184,3 +184,17 @@ def test_stream_with_nlms_canceller():
     rf, sf = O.overlap_frames(a, C, C // 2), O.overlap_frames(cleaned, C, C // 2)
     exp = np.stack([O.fast_xambg(x, y, R, F, 2 * C, w)[:, :, 0] for x, y in zip(rf, sf)])
     assert got.shape == exp.shape and rel_err(got, exp) < 1e-4
+
+
+def test_cfg1_pipeline_against_reference_output():
+    """BASELINE config 1 (the reference's own CPU-runnable case) end to end: three 131 072-sample chunks -> LS x5
+    bins -> the middle overlapped 256 x 257 frame, against the map the reference itself produced.  At this length
+    the reference's float32 correlation noise stays below the 1e-4 bar on every cell."""
+    import torch
+    from passiveradar_amd import scene
+    from passiveradar_amd.stream import HipBackend, StreamProcessor
+    g = load_golden("pipeline_cfg1")
+    n, R, F, fs = int(g["N"]), int(g["R"]), int(g["F"]), float(g["fs"])
+    a, s = scene.make_stream(3, n // 2, fs, R, int(g["seed"]))
+    X = StreamProcessor(HipBackend(n, R, F, fs, batch=3)).process(a, s)[int(g["frame_index"])].cpu().numpy()
+    assert X.shape == g["out"].shape and rel_err(X, g["out"]) < 1e-4

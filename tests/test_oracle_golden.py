@@ -233,3 +233,12 @@ def test_ls_cfg1_chunk():
     scale = np.abs(g["head"]).max()
     assert np.abs(out[::7] - g["out_sub"]).max() / scale < 1e-5
     assert np.abs(out[:600] - g["head"]).max() / scale < 1e-5 and np.abs(out[-600:] - g["tail"]).max() / scale < 1e-5
+
+
+def test_cfg1_pipeline_restatement():
+    """config 1 end to end: the oracle's main.py:169-194 restatement against the reference's own frame"""
+    g = load_golden("pipeline_cfg1")
+    n, R, F, fs = int(g["N"]), int(g["R"]), int(g["F"]), float(g["fs"])
+    a, s = scene.make_stream(3, n // 2, fs, R, int(g["seed"]))
+    frames = O.process_stream(a, s, n, R, F, fs)
+    assert rel_err(frames[:, :, int(g["frame_index"])], g["out"]) < 1e-4
