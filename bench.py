@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- CAF frames/s of the range-Doppler hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--workload cfg2|cfg2p2|cfg1|cfg3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg4|cfg5|cfg3|cfg1|cfg2p2] [--frames B]
 
-A *step* is one pass of the hot path (main.py:169-194 semantics) over one batch of B frames per
-GPU of synthetic two-channel complex64 IQ already resident in HBM: LS_Filter_Multiple on the B
-hop chunks (5 Doppler bins) + fast_xambg on the B 50 %-overlapped CPI frames.  Default workload =
-BASELINE.json configs[1]: 2.4 MS/s, 1 s CPI (N = 2 400 000), 256 range x 512 Doppler, LS clutter
-filter.  For N>1 (launched by torch.distributed.run, one rank per GPU) every rank processes its
-own B frames (weak scaling, no data-path collective); the frame maps are gathered with one RCCL
-gather per step *outside* nothing -- it is inside the timed region, as the real pipeline needs it.
+A *step* is one pass of the hot path (main.py:169-194 semantics) over one batch of B frames per GPU
+of synthetic two-channel complex64 IQ already resident in HBM: LS_Filter_Multiple on the B hop chunks
+(5 Doppler bins) + fast_xambg on the B 50 %-overlapped CPI frames, in sub-batches of 256.
+
+Workloads (BASELINE.json configs):
+  cfg2 (default) 2.4 MS/s, 1 s CPI (N = 2 400 000), 256 range x 512 Doppler, LS canceller.  N>1: every
+                 rank processes its own B frames (weak scaling); the maps go to rank 0 with one RCCL
+                 gather per 256-frame sub-batch, inside the timed region, overlapped with compute.
+  cfg4           a 600 s stream of cfg-2 IQ = 1199 overlapped frames (main.py:116-120), frames sharded
+                 contiguously over the ranks (stream.plan_shard: strong scaling, one halo chunk each side
+                 re-filtered locally), ONE gather of the maps per pass.  A step = the whole stream.
+  cfg5           20 MS/s, N = 2^23, 2048 x 2048, four illuminators against one surveillance channel, CAF
+                 only; with N>1 the illuminators are sharded over the ranks (min(N,4)-way) and the frame
+                 groups over what is left; the 33.6 MB surfaces stay on the GPU that made them.
+  cfg3           10 MS/s, N = 5e6, 1024 x 1024, NLMS canceller (one wavefront per hop chunk).
+  cfg1, cfg2p2   the reference's own CPU-sized case / the power-of-two variant of cfg2.
 
 One JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     : dominant kernel's algorithmic bytes / its average launch time (HIP events on the
-                 launch stream), against 8 TB/s HBM peak
+  roofline     : dominant kernel's algorithmic bytes (or flops) / its average launch time (HIP events on
+                 the launch stream), against the 8 TB/s HBM peak (or the 157.3 TFLOP/s fp32 vector peak
+                 for the serial NLMS recursion, which is VALU-issue-bound)
   cpu_baseline : the reference's CPU path (oracle restatement issuing the same NumPy/SciPy calls,
-                 SciPy-1.15 np.roots artefact left out) timed on this box's host cores for a
-                 bounded sample (rank 0, N=1 only)
+                 SciPy-1.15 np.roots artefact left out) MEASURED on this box's host cores: one core,
+                 and one frame per worker process on min(cores, 32) workers (rank 0, N=1 only)
 """
 import argparse
 import json
@@ -31,88 +41,142 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector peak
+MIN_TIMED_SECONDS = 5.0        # auto-sized runs time at least this long
 
 WORKLOADS = {
-    # name: (Fs, N, R, F, clutter)
-    "cfg2": (2.4e6, 2400000, 256, 512, "ls"),
-    "cfg2p2": (2.4e6, 2097152, 256, 512, "ls"),
-    "cfg1": (262184.87, 262144, 256, 256, "ls"),
-    "cfg3": (1.0e7, 5000000, 1024, 1024, "nlms"),
+    # name: (Fs, N, R, F, clutter, default frames per GPU per step)
+    "cfg2": (2.4e6, 2400000, 256, 512, "ls", 5120),
+    "cfg2p2": (2.4e6, 2097152, 256, 512, "ls", 2048),
+    "cfg1": (262184.87, 262144, 256, 256, "ls", 4096),
+    "cfg3": (1.0e7, 5000000, 1024, 1024, "nlms", 1024),
+    # config 4: 600 s of cfg-2 IQ, hop 0.5 s -> 1200 chunks, trimmed by one (main.py:116-120) -> 1199 frames
+    "cfg4": (2.4e6, 2400000, 256, 512, "ls", 1199),
     # config 5: 20 MS/s, 2048 x 2048, four illuminators against one surveillance channel, CAF only
-    "cfg5": (2.0e7, 1 << 23, 2048, 2048, None),
+    "cfg5": (2.0e7, 1 << 23, 2048, 2048, None, 8),
 }
 N_ILLUMINATORS = {"cfg5": 4}
+SUB_BATCH = 256                # frames per CAF launch / per gather; LS launches take half of it
 
 
-def synth_stream(torch, nchunks, C, fs, R, seed, device):
-    """Device-side synthetic scene with the structure of passiveradar_amd.scene.make_scene."""
+def synth_segment(torch, nchunks, C, fs, R, seed, device, t0=0.0):
+    """Device-side synthetic scene with the structure of passiveradar_amd.scene.make_scene
+    (delays are circular shifts inside the segment)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     n = nchunks * C
     ref = torch.view_as_complex(torch.randn((n, 2), generator=g, device=device, dtype=torch.float32)
                                 * np.float32(np.sqrt(0.5)))
-    noise = torch.view_as_complex(torch.randn((n, 2), generator=g, device=device, dtype=torch.float32)
-                                  * np.float32(np.sqrt(0.5)))
     srv = torch.roll(ref, 2) + 0.3 * torch.roll(ref, 9) + 0.1 * torch.roll(ref, 40)
-    t = torch.arange(n, device=device, dtype=torch.float64) / fs
+    t = torch.arange(n, device=device, dtype=torch.float64) / fs + t0
     for d, fd, a in ((60, 80.0, 0.01), (R // 2, -35.0, 0.003), (R - 5, 120.0, 0.003)):
         ph = (2 * np.pi * fd) * t
         rot = torch.complex(torch.cos(ph), torch.sin(ph)).to(torch.complex64)
         srv = srv + a * torch.roll(ref, d) * rot
+    del t
+    noise = torch.view_as_complex(torch.randn((n, 2), generator=g, device=device, dtype=torch.float32)
+                                  * np.float32(np.sqrt(0.5)))
     srv = srv + 0.003 * noise
-    return ref.contiguous(), srv.to(torch.complex64).contiguous()
+    return ref, srv.to(torch.complex64)
 
 
-def cpu_baseline(workload, seconds_budget=30.0):
-    """Reference CPU path on this host (1 process, 1 thread): one CAF frame + one LS hop."""
+def synth_padded(torch, nchunks, C, fs, R, seed, device, seg_chunks=128, add_to=None):
+    """[C/2 zeros | nchunks chunks | C/2 zeros] reference and surveillance streams, generated segment by
+    segment (a 5120-chunk stream is 49 GB per channel; the generator's temporaries are kept to one
+    segment).  add_to: an existing padded surveillance stream to accumulate into (further illuminators)."""
+    ref_pad = torch.zeros(nchunks * C + C, dtype=torch.complex64, device=device)
+    srv_pad = add_to if add_to is not None else torch.zeros(nchunks * C + C, dtype=torch.complex64, device=device)
+    seg_chunks = max(1, min(seg_chunks, (1 << 28) // C))         # <= 2 GB per temporary
+    for c0 in range(0, nchunks, seg_chunks):
+        m = min(seg_chunks, nchunks - c0)
+        a, s = synth_segment(torch, m, C, fs, R, seed * 1000003 + c0, device, t0=c0 * C / fs)
+        lo = C // 2 + c0 * C
+        ref_pad[lo:lo + m * C] = a
+        srv_pad[lo:lo + m * C] += s
+        del a, s
+    return ref_pad, srv_pad
+
+
+# ---- CPU baseline: the reference's NumPy/SciPy path on this box's host cores ------------------------
+def _cpu_frame_worker(args):
+    """One whole frame of the workload (one LS hop / NLMS sample + one fast_xambg) in this process."""
+    os.environ["OMP_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = "1"
+    workload, lags, seed_off = args
+    from scipy.signal import get_window
     from oracle import np_oracle as O
     from passiveradar_amd import scene
-    from scipy.signal import get_window
-    fs, n, R, F, clutter = WORKLOADS[workload]
-    # bounded sample: a full frame at cfg2 costs ~12-16 s; larger configs are cut to fewer lags
-    lags = R
-    if workload == "cfg3":
-        lags = 63            # 64 of 1025 lag columns, scaled back up below
-    ref, srv = scene.make_scene(n, fs, R, scene.scene_seed(2))
+    fs, n, R, F, clutter, _ = WORKLOADS[workload]
+    ref, srv = scene.make_scene(n, fs, R, scene.scene_seed(2) + seed_off)
     w = get_window(("kaiser", 5.0), n)
+    C = n // 2
     t0 = time.perf_counter()
     O.fast_xambg_libcalls(ref, srv, lags, F, w)
     t_caf = (time.perf_counter() - t0) * (R + 1) / (lags + 1)
-    C = n // 2
     t0 = time.perf_counter()
     if clutter == "ls":
         O.LS_Filter_Multiple_libcalls(ref[:C], srv[:C], R, fs, [0, 1, -1, 2, -2])
-        t_ls = time.perf_counter() - t0
-        ls_note = "1 LS_Filter_Multiple hop (5 bins)"
-    else:
+        t_cl = time.perf_counter() - t0
+    elif clutter == "nlms":
         from oracle import c_oracle
         m = 20000
         c_oracle.nlms(ref[:m], srv[:m], R, 0.02, 10)
-        t_ls = (time.perf_counter() - t0) * (C / (m - R - 10))
-        ls_note = "NLMS on 20k samples (C twin), scaled to one hop"
+        t_cl = (time.perf_counter() - t0) * (C / (m - R - 10))
+    else:
+        t_cl = 0.0
+    return t_caf, t_cl
+
+
+def cpu_baseline(workload, max_workers=32):
+    """(i) one core, bounded sample; (ii) all cores: one frame per worker process on min(cores, 32) workers."""
+    import multiprocessing as mp
+    fs, n, R, F, clutter, _ = WORKLOADS[workload]
     cores = os.cpu_count() or 1
+    nill = N_ILLUMINATORS.get(workload, 1)
+    # bounded one-core sample: 64 of the lag columns (whole LS hop), scaled to the full lag count
+    lags1 = min(R, 63)
+    t_caf1, t_cl1 = _cpu_frame_worker((workload, lags1, 0))
+    one = 1.0 / (nill * t_caf1 + t_cl1)
+    W = max(1, min(cores, max_workers))
+    lagsW = R if workload in ("cfg2", "cfg2p2", "cfg1", "cfg4") else min(R, 63)   # whole frames where they take < 1 min
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(W) as pool:
+        per = pool.map(_cpu_frame_worker, [(workload, lagsW, i) for i in range(W)])
+    wall = time.perf_counter() - t0
+    # every worker did one frame's worth of (scaled) work concurrently; throughput = W / the slowest worker
+    slow = max(nill * a + b for a, b in per)
+    allc = W / slow
+    note_cl = {"ls": "1 LS_Filter_Multiple hop (5 bins)", "nlms": "NLMS on 20k samples (C twin), scaled to one hop",
+               None: "no canceller"}[clutter]
     return {
-        "value": 1.0 / (t_caf + t_ls), "unit": "frames/s", "cores": 1, "kind": "port",
-        "sample": f"1 fast_xambg frame ({lags + 1} of {R + 1} lag columns timed) + {ls_note}, "
-                  f"NumPy/SciPy calls of the reference, np.roots artefact bypassed",
-        "caf_only_value": 1.0 / t_caf, "caf_seconds": t_caf, "clutter_seconds": t_ls,
-        "host_cores": cores, "ideal_all_cores_value": cores / (t_caf + t_ls),
+        "value": allc, "unit": "frames/s", "cores": W, "kind": "port",
+        "sample": f"{W} worker processes x 1 frame each, concurrently ({lagsW + 1} of {R + 1} lag columns timed per "
+                  f"fast_xambg, scaled; {note_cl}; 1 thread per process); NumPy/SciPy calls of the reference, "
+                  f"np.roots artefact bypassed",
+        "one_core_value": one, "one_core_caf_seconds": t_caf1, "one_core_clutter_seconds": t_cl1,
+        "one_core_sample": f"{lags1 + 1} of {R + 1} lag columns + {note_cl}",
+        "host_cores": cores, "workers": W, "workers_wall_seconds": wall,
+        "slowest_worker_frame_seconds": slow,
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 20 for the default workload, else sized to >= 5 s)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=256, help="frames (= hop chunks) per GPU per step")
+    ap.add_argument("--frames", type=int, default=None, help="frames (= hop chunks) per GPU per step")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--sub-batch", type=int, default=SUB_BATCH, help="frames per CAF launch and per gather")
     ap.add_argument("--caf-method", type=int, default=0, help="0 auto, 1 direct, 2 fft")
-    ap.add_argument("--doppler", type=int, default=0, help="0 auto, 1 rocfft, 2 fused")
     ap.add_argument("--ls-method", type=int, default=0, help="0 auto, 1 time-domain, 2 FFT, 3 FFT + spectrum cache")
-    ap.add_argument("--nsub", type=int, default=2, help="LS sub-batches per step when stages are pipelined")
+    ap.add_argument("--nsub", type=int, default=2, help="LS sub-batches per CAF sub-batch when stages are pipelined")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run LS and CAF back to back on one stream instead of pipelining sub-batches on two")
+    ap.add_argument("--gather", default="auto", choices=["auto", "prc", "torch", "none"],
+                    help="N>1: prc = prc_gather_frames (RCCL through the C ABI), torch = torch.distributed.gather, "
+                         "auto = prc when every rank could create the communicator, else torch")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-clutter", action="store_true", help="CAF only (reported as a different metric)")
     args = ap.parse_args()
@@ -133,49 +197,125 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     _lib.require_gpu()
 
-    fs, n, R, F, clutter = WORKLOADS[args.workload]
+    wl = args.workload
+    fs, n, R, F, clutter, B_default = WORKLOADS[wl]
     if args.no_clutter:
         clutter = None
-    B = args.frames
     C = n // 2
-    be = prstream.HipBackend(n, R, F, fs, clutter=clutter, batch=B, device=device,
-                             caf_method=args.caf_method, doppler_method=args.doppler, overlap=not args.no_overlap, ls_method=args.ls_method, nsub=args.nsub)
-    ref, srv = synth_stream(torch, B, C, fs, R, 20260926 + rank, device)
-    ref_pad = be.padded(ref)
-    srv_pad = be.padded(srv)
-    del ref, srv
-    nill = N_ILLUMINATORS.get(args.workload, 1)
-    # further illuminators (cfg5): independent white references; the surveillance channel carries every
-    # illuminator's scene
-    extra_refs = []
-    for i in range(nill - 1):
-        er, es = synth_stream(torch, B, C, fs, R, 777 + 13 * i + rank, device)
-        extra_refs.append(be.padded(er))
-        srv_pad += be.padded(es)
-        del er, es
-    shard = prstream.Shard(rank, world, B * world, rank * B, (rank + 1) * B, 0, B)
+    sub = max(1, args.sub_batch)
+    nill = N_ILLUMINATORS.get(wl, 1)
+    strong = wl == "cfg4"
 
-    pending = []                                   # (frames kept alive, result, work) of the gather in flight
+    # ---- what this rank owns ----------------------------------------------------------------------
+    ill_ways = min(world, nill) if nill > 1 else 1            # illuminator shards (cfg5)
+    groups = world // ill_ways if nill > 1 else world         # frame groups
+    my_ills = [i for i in range(nill) if i % ill_ways == rank % ill_ways]
+    if strong:
+        total = args.frames or B_default                      # frames in the whole stream
+        shard = prstream.plan_shard(total, rank, world)
+        nlocal, nframes, first = shard.nlocal_chunks, shard.nframes, shard.frame_offset(shard.frame_lo, C)
+        B = nframes
+        frames_per_step_total = total
+    else:
+        B = args.frames or B_default
+        if nill > 1:
+            B = B * ill_ways                                  # a frame group works through ill_ways * B frames ...
+        nlocal, nframes, first = B, B, 0
+        frames_per_step_total = B * groups if nill > 1 else B * world   # ... each rank its own illuminators
+    batch = min(sub, max(nframes, 1))
+    be = prstream.HipBackend(n, R, F, fs, clutter=clutter, batch=batch, device=device,
+                             caf_method=args.caf_method, overlap=not args.no_overlap,
+                             ls_method=args.ls_method, nsub=args.nsub)
+
+    # ---- synthetic IQ resident in HBM --------------------------------------------------------------
+    seed0 = 20260926 + (rank if not strong else 0)
+    if strong:
+        # every rank generates the chunks of ITS shard only (chunk_lo..chunk_hi); segment seeds are keyed by
+        # the global chunk index so the stream is the same whatever the sharding
+        ref_pad = torch.zeros(max(nlocal, 1) * C + C, dtype=torch.complex64, device=device)
+        srv_pad = torch.zeros_like(ref_pad)
+        seg = 64
+        for g0 in range((shard.chunk_lo // seg) * seg, shard.chunk_hi, seg):
+            a, s = synth_segment(torch, seg, C, fs, R, seed0 * 1000003 + g0, device, t0=g0 * C / fs)
+            lo, hi = max(g0, shard.chunk_lo), min(g0 + seg, shard.chunk_hi)
+            dst = C // 2 + (lo - shard.chunk_lo) * C
+            ref_pad[dst:dst + (hi - lo) * C] = a[(lo - g0) * C:(hi - g0) * C]
+            srv_pad[dst:dst + (hi - lo) * C] = s[(lo - g0) * C:(hi - g0) * C]
+            del a, s
+        refs = [ref_pad]
+    elif nill > 1:
+        # the surveillance channel carries every illuminator's scene; a rank keeps only the
+        # reference channels of the illuminators it owns
+        g = rank // ill_ways
+        srv_pad, refs = None, []
+        for i in range(nill):
+            r_i, srv_pad = synth_padded(torch, B, C, fs, R, 777 + 13 * i + 1000 * g, device, add_to=srv_pad)
+            if i in my_ills:
+                refs.append(r_i)
+            del r_i
+    else:
+        ref_pad, srv_pad = synth_padded(torch, B, C, fs, R, seed0, device)
+        refs = [ref_pad]
+    torch.cuda.synchronize()
+
+    # ---- the one collective: gather of the maps to rank 0 ---------------------------------------------
+    gather_mode = args.gather if (world > 1 and nill == 1) else "none"
+    comm = None
+    if gather_mode in ("auto", "prc"):
+        ok = 1
+        try:
+            comm = prstream.FrameComm.from_torch_distributed()
+        except Exception as e:                       # noqa: BLE001 -- any failure falls back (auto) or aborts (prc)
+            ok, comm = 0, None
+            if gather_mode == "prc":
+                raise
+            print(f"[rank {rank}] prc_comm_create failed ({e}); gathering through torch.distributed", file=sys.stderr)
+        flag = torch.tensor([ok], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            comm = None
+        gather_mode = "prc" if comm is not None else "torch"
+    s_comm = torch.cuda.Stream(device=device) if gather_mode != "none" else None
+    gsize = nframes if strong else batch            # frames per gather from this rank
+    if gather_mode != "none":
+        if strong:
+            gshard = shard
+        else:
+            gshard = prstream.Shard(rank, world, gsize * world, rank * gsize, (rank + 1) * gsize, 0, gsize)
+        recv = [torch.empty((gshard.nchunks, F, R + 1), dtype=torch.complex64, device=device) if rank == 0 else None
+                for _ in range(2)]                   # two persistent receive buffers, used alternately
+    pending = [None, None]                           # work handle of the gather that last used each buffer
+    gcount = [0]
+
+    def gather(block):
+        k = gcount[0] & 1
+        gcount[0] += 1
+        if pending[k] is not None:
+            pending[k][1].wait()
+        s_comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_comm):
+            res, work = prstream.gather_frames(block, gshard, async_op=True, out=recv[k], comm=comm, stream=s_comm)
+        block.record_stream(s_comm)
+        pending[k] = (block, work)
 
     def drain():
-        while pending:
-            _, _, work = pending.pop()
-            if work is not None:
-                work.wait()
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k][1].wait()
+                pending[k] = None
+
+    outs = [torch.empty((max(nframes, 1), F, R + 1), dtype=torch.complex64, device=device) for _ in refs]
 
     def step():
-        frames = be.run(ref_pad, srv_pad, B, 0, B)
-        for er in extra_refs:                      # further illuminators share the surveillance channel
-            be.run(er, srv_pad, B, 0, B)
-        if world > 1:
-            # the only collective: gather of this step's maps to rank 0 (RCCL over xGMI), issued
-            # asynchronously so that it overlaps the next step's kernels; every gather is complete
-            # before the timed region closes (drain() in fence())
-            drain()
-            res, work = prstream.gather_frames(frames, shard, async_op=True)
-            pending.append((frames, res, work))
-            return res
-        return frames
+        for r_i, out in zip(refs, outs):             # further illuminators share the surveillance channel
+            if nframes:
+                be.run(r_i, srv_pad, nlocal, first, nframes, out=out)
+        if gather_mode != "none":
+            if strong:
+                gather(outs[0][:nframes])
+            else:
+                for f0 in range(0, nframes, gsize):
+                    gather(outs[0][f0:f0 + gsize])
 
     def fence():
         drain()
@@ -183,11 +323,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         step()
     fence()
+    steps = args.steps
+    if steps is None:
+        if wl == "cfg2":
+            steps = 20
+        else:                                        # size the timed region to >= MIN_TIMED_SECONDS
+            t0 = time.perf_counter()
+            step()
+            fence()
+            probe = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(probe, op=dist.ReduceOp.MAX)
+            steps = int(min(max(np.ceil(MIN_TIMED_SECONDS / max(float(probe.item()), 1e-6)), 3), 2000))
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     dt = time.perf_counter() - t0
@@ -195,111 +347,149 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    frames_total = B * world * args.steps          # a multi-illuminator frame = all its CAF surfaces
-    value = frames_total / dt
+    value = frames_per_step_total * steps / dt      # a multi-illuminator frame = all its CAF surfaces
 
     # ---- per-kernel timing with HIP events on the launch stream (rank 0) --------------------
     result = None
     if rank == 0:
-        reps = max(3, args.steps)
+        reps = 5
+        nb = min(batch, nframes)
         ev = lambda: torch.cuda.Event(enable_timing=True)
         kt = {}
-        clean = be.clean(ref_pad, srv_pad, B)
-        out = torch.empty((B, F, R + 1), dtype=torch.complex64, device=device)
+        ref0 = refs[0]
+        clean = be.clean(ref0, srv_pad, min(nlocal, nb + 1))
+        out = outs[0]
         s = _lib.torch_stream_ptr()
         e0, e1, e2 = [], [], []
         for _ in range(reps):
             a, b, c = ev(), ev(), ev()
             a.record()
-            be.caf.execute_segments(ref_pad, clean, B, C, n, be.window, s)
+            be.caf.execute_segments(ref0[first:], clean[first:], nb, C, n, be.window, s)
             b.record()
-            be.caf.execute_doppler(out, B, s)
+            be.caf.execute_doppler(out, nb, s)
             c.record()
             e0.append(a); e1.append(b); e2.append(c)
         torch.cuda.synchronize()
         kt["caf_segments"] = {"ms": float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)])),
-                              "launches_per_step": 1,
-                              "bytes": B * (20.0 * n + 8.0 * F * (R + 1))}
+                              "launches_per_step": -(-nframes // batch) * len(refs), "bound": "hbm",
+                              "work": nb * (20.0 * n + 8.0 * F * (R + 1))}
         kt["caf_doppler"] = {"ms": float(np.mean([b.elapsed_time(c) for b, c in zip(e1, e2)])),
-                             "launches_per_step": 1, "bytes": B * 16.0 * F * (R + 1)}
+                             "launches_per_step": -(-nframes // batch) * len(refs), "bound": "hbm",
+                             "work": nb * 16.0 * F * (R + 1)}
         if clutter == "ls":
             be.ls.set_profiling(True)
-            nb_ls = min(B, be.sub)
+            nb_ls = min(nlocal, be.sub)                         # blocks behind one LS launch
             acc = np.zeros(3)
             for _ in range(reps):
-                be._clean_range(ref_pad, srv_pad, clean, 0, nb_ls, s)
+                be._clean_range(ref0, srv_pad, clean, 0, nb_ls, s)
                 ms3, k3 = be.ls.get_profile()
                 acc += ms3
             be.ls.set_profiling(False)
             acc /= reps
-            nb = min(B, be.sub)                                # blocks behind one LS launch
             T = R + 10
             fused = k3[0] == 1 and k3[2] > 1                   # cached-spectrum chain: corr(i+1) inside FIR(i)
-            nsub = -(-B // nb)                                 # LS executes (sub-batches) per step
-            k3 = tuple(k * nsub for k in k3)
-            acc = acc * nsub
-            kt["ls_correlate"] = {"ms": acc[0] / k3[0], "launches_per_step": k3[0], "bytes": nb * 16.0 * C}
-            kt["ls_solve"] = {"ms": acc[1] / k3[1], "launches_per_step": k3[1],
-                              "bytes": nb * (T * T * 16.0 + 64 * 2 * T * 8.0)}
-            nb_bins = k3[2] // nsub
+            execs = -(-nlocal // nb_ls)                        # LS executes per step
+            kt["ls_correlate"] = {"ms": acc[0] / k3[0], "launches_per_step": k3[0] * execs, "bound": "hbm",
+                                  "work": nb_ls * 16.0 * C}
+            kt["ls_solve"] = {"ms": acc[1] / k3[1], "launches_per_step": k3[1] * execs, "bound": "latency",
+                              "work": nb_ls * (T * T * 16.0 + 64 * 2 * T * 8.0)}
+            nb_bins = k3[2]
             fir_bytes = 24.0 * C + (16.0 * C * (nb_bins - 1) / nb_bins if fused else 0.0)
-            kt["ls_fir_subtract"] = {"ms": acc[2] / k3[2], "launches_per_step": k3[2], "bytes": nb * fir_bytes}
+            kt["ls_fir_subtract"] = {"ms": acc[2] / k3[2], "launches_per_step": k3[2] * execs, "bound": "hbm",
+                                     "work": nb_ls * fir_bytes}
         elif clutter == "nlms":
             a, b = ev(), ev()
             a.record()
-            be.clean(ref_pad, srv_pad, B)
+            be.clean(ref0, srv_pad, nlocal)
             b.record()
             torch.cuda.synchronize()
-            kt["nlms"] = {"ms": a.elapsed_time(b), "launches_per_step": 1, "bytes": B * 24.0 * C}
+            T = R + 10
+            # per step and stream: e = d - w^H u, u^H u, w += mu u conj(e)/(u^H u): 2 T complex MACs = 16 T flops
+            # (+ the energy slide); SURVEY 8d counts ~20 T
+            kt["nlms"] = {"ms": a.elapsed_time(b), "launches_per_step": 1, "bound": "valu",
+                          "work": nlocal * float(C - T) * 20.0 * T,
+                          "streams": nlocal, "samples_per_s_per_stream": (C - T) / (a.elapsed_time(b) * 1e-3)}
         dom = max(kt, key=lambda k_: kt[k_]["ms"] * kt[k_]["launches_per_step"])
-        achieved = kt[dom]["bytes"] / (kt[dom]["ms"] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
-                if traffic is not None:
-                    # file holds bytes per chunk/frame; an LS launch covers one sub-batch, a CAF launch B frames
-                    traffic = traffic * (min(B, be.sub) if dom.startswith("ls_") else B)
-            except Exception:
-                traffic = None
-        per_frame_bytes = 20.0 * n + 8.0 * F * (R + 1) + (200.0 * C if clutter == "ls" else
-                                                           (24.0 * C if clutter == "nlms" else 0.0))
+        d = kt[dom]
+        if d["bound"] == "valu":
+            achieved = d["work"] / (d["ms"] * 1e-3) / 1e12
+            roof = {"kernel": dom, "bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / VALU_PEAK_TFLOPS, "traffic": None,
+                    "note": "sample-recursive NLMS: one wavefront per stream, VALU-issue-bound; "
+                            f"{d['samples_per_s_per_stream']:.3g} samples/s/stream x {d['streams']} streams"}
+        else:
+            achieved = d["work"] / (d["ms"] * 1e-3) / 1e9
+            traffic, tsrc = None, None
+            tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    traffic = tj.get("cfg2" if wl == "cfg4" else wl, {}).get(dom)
+                    if traffic is not None:
+                        # the file holds bytes per chunk / frame; an LS launch covers one LS sub-batch, a CAF launch nb frames
+                        traffic = traffic * (min(nlocal, be.sub) if dom.startswith("ls_") else nb)
+                        tsrc = tj.get("_source", "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier "
+                                                 "run of this command; not measured by this run)")
+                except Exception:
+                    traffic = None
+            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc}
+        caf_bytes = 20.0 * n + 8.0 * F * (R + 1)
+        if nill > 1:                                            # srv and the window are shared by the illuminators
+            per_frame_bytes = nill * 8.0 * n + 8.0 * n + 4.0 * n + nill * 8.0 * F * (R + 1)
+        else:
+            per_frame_bytes = caf_bytes + (200.0 * C if clutter == "ls" else (24.0 * C if clutter == "nlms" else 0.0))
         m, dp = be.caf.method, be.caf.doppler
+        if strong:
+            par = (f"{frames_per_step_total} frames of one stream sharded contiguously x{world} (strong), "
+                   f"one gather of the maps per pass ({gather_mode})") if world > 1 else "single GPU, whole stream"
+        elif nill > 1:
+            par = (f"{nill} illuminators sharded {ill_ways}-way x {groups} frame group(s), surfaces stay on their GPU"
+                   if world > 1 else f"single GPU, {nill} illuminators")
+        else:
+            par = f"frame-sharded x{world}, gather of maps to rank 0 per {gsize} frames ({gather_mode})" if world > 1 \
+                else "single GPU"
         result = {
             "metric": "CAF frames/sec (1s CPI @ 2.4 MS/s, 256 range x 512 Doppler); HBM GB/s %peak"
-                      if args.workload == "cfg2" else f"CAF frames/sec ({args.workload})",
-            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                      if wl in ("cfg2", "cfg4") else f"CAF frames/sec ({wl})",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": steps,
+            "warmup": max(args.warmup, 1), "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: Fs={fs:g} N={n} R={R} F={F} clutter="
+            "config": {"workload": f"{wl}: Fs={fs:g} N={n} R={R} F={F} clutter="
                                    f"{clutter or 'none'}{' x5 Doppler bins, T=%d' % (R + 10) if clutter == 'ls' else ''}, "
-                                   f"{B} overlapped frames/GPU/step (hop N/2), Kaiser(5) window",
-                       "frames_per_gpu_per_step": B,
+                                   + (f"{frames_per_step_total}-frame stream (600 s), " if strong else
+                                      f"{B} overlapped frames/GPU/step, ")
+                                   + f"sub-batches of {batch} (hop N/2), Kaiser(5) window"
+                                   + (f", {nill} illuminators / frame" if nill > 1 else ""),
+                       "frames_per_gpu_per_step": nframes, "frames_per_step_total": frames_per_step_total,
                        "arithmetic": "complex64 streams, f32 FFT butterflies, f64 Levinson-Durbin / tap solves",
                        "caf_method": {1: "direct", 2: "fft"}.get(m, m),
-                       "doppler_method": {1: "rocfft", 2: "fused"}.get(dp, dp),
-                       "parallelism": f"frame-sharded x{world}, RCCL gather of maps" if world > 1 else "single GPU"},
+                       "doppler_method": {1: "rocfft"}.get(dp, dp),
+                       "parallelism": par},
+            "timed_seconds": dt,
             "hbm_algorithmic_GBps": per_frame_bytes * value / world / 1e9,
             "hbm_frac_of_peak": per_frame_bytes * value / world / 1e9 / HBM_PEAK_GBS,
             "hbm_frac_of_copy_ceiling": per_frame_bytes * value / world / 1e9 / 6290.0,   # MI355X_MICROARCH.md: ~6.3 TB/s achievable
-            "kernels": {k_: {"avg_ms_per_launch": v["ms"], "launches_per_step": v["launches_per_step"],
-                             "algorithmic_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9} for k_, v in kt.items()},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic},
+            "kernels": {k_: {"avg_ms_per_launch": v["ms"], "launches_per_step": v["launches_per_step"], "bound": v["bound"],
+                             ("algorithmic_TFLOPs" if v["bound"] == "valu" else "algorithmic_GBps"):
+                                 v["work"] / (v["ms"] * 1e-3) / (1e12 if v["bound"] == "valu" else 1e9)}
+                        for k_, v in kt.items()},
+            "roofline": roof,
         }
         caf_ms = kt["caf_segments"]["ms"] + kt["caf_doppler"]["ms"]
-        result["caf_only_frames_per_s_per_gpu"] = B / (caf_ms * 1e-3)
-        result["caf_only_hbm_frac"] = (20.0 * n + 8.0 * F * (R + 1)) * B / (caf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        result["caf_only_frames_per_s_per_gpu"] = nb / (caf_ms * 1e-3)
+        result["caf_only_hbm_frac"] = caf_bytes * nb / (caf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if world == 1 and not args.no_cpu:
-            cb = cpu_baseline(args.workload)
+            cb = cpu_baseline(wl)
             result["cpu_baseline"] = cb
-            result["speedup_vs_cpu_1core"] = value / cb["value"]
-            result["speedup_vs_cpu_ideal_all_cores"] = value / cb["ideal_all_cores_value"]
+            result["speedup_vs_cpu_all_cores_measured"] = value / cb["value"]
+            result["speedup_vs_cpu_1core"] = value / cb["one_core_value"]
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRC_VERSION 100
+#define PRC_VERSION 200
 
 typedef enum prc_status {
     PRC_OK = 0,
@@ -64,8 +64,8 @@ typedef enum prc_caf_method {
 
 typedef enum prc_doppler_method {
     PRC_DOPPLER_AUTO = 0,
-    PRC_DOPPLER_ROCFFT = 1, /* batched 1-D rocFFT over the slow-time axis (any freq_bins)     */
-    PRC_DOPPLER_FUSED = 2   /* in-LDS radix FFT + fftshift + transpose (power-of-two bins)    */
+    PRC_DOPPLER_ROCFFT = 1  /* batched 1-D rocFFT over the slow-time axis (any freq_bins) +
+                               one fftshift/transpose kernel (:89)                           */
 } prc_doppler_method;
 
 typedef struct prc_caf_desc {
@@ -224,6 +224,27 @@ int prc_decimate_iir(const void* x, int64_t n, const prc_iir_desc* iir, void* y,
  * (*argmax_out - nl) * nd.  Synchronises `stream` before returning. */
 int prc_channel_offset(const void* s1, int64_t n1, const void* s2, int64_t n2, const prc_iir_desc* iir,
                        int64_t nl, float* xc_out, int64_t* n_xc, int64_t* argmax_out, void* stream);
+
+/* ---- frame gather over xGMI: main.py:213-224 (da.store / to_zarr) for sharded frames ---- */
+/* CPI frames shard contiguously over the GPUs of a node (one process per GPU); the only exchange of
+ * the path is the gather of every rank's [frames][freq_bins][range_bins+1] complex64 block to one
+ * root, as a group of RCCL point-to-point transfers (ncclSend on the peers, one ncclRecv per peer on
+ * the root), each on its own xGMI link.  RCCL is bound at run time (dlopen librccl.so.1); without it
+ * these entry points return PRC_EUNSUPPORTED and everything else still works.
+ *   rank 0:      prc_comm_unique_id(id)  -> ship the 128 bytes to every rank (any side channel)
+ *   every rank:  prc_set_device(local_gpu); prc_comm_create(&comm, id, rank, world)   (collective)
+ *   every pass:  prc_gather_frames(comm, my_frames, frames_per_rank, F*(R+1), all_frames, 0, stream) */
+#define PRC_COMM_ID_BYTES 128
+typedef struct prc_comm prc_comm;
+int prc_comm_unique_id(void* id_host);                       /* HOST buffer of PRC_COMM_ID_BYTES      */
+int prc_comm_create(prc_comm** comm, const void* id_host, int32_t rank, int32_t world);
+int prc_comm_destroy(prc_comm* comm);
+/* send: this rank's frames_per_rank_host[rank] frames of frame_elems complex64 (DEVICE).  recv (root
+ * only, DEVICE): sum(frames_per_rank_host) frames, rank r's block at frame offset sum_{q<r}.  Blocks may
+ * be ragged or empty.  Enqueued on `stream`; nothing synchronises.  The root's own block is a device
+ * copy (skipped when send already points at its slot in recv). */
+int prc_gather_frames(prc_comm* comm, const void* send, const int64_t* frames_per_rank_host,
+                      int64_t frame_elems, void* recv, int32_t root, void* stream);
 
 #ifdef __cplusplus
 }

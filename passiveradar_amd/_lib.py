@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("PRCORE_LIB", os.path.join(_HERE, "libprcore.so"))   #
 
 PRC_OK, PRC_EINVAL, PRC_ESHAPE, PRC_EHIP, PRC_EROCFFT, PRC_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 CAF_AUTO, CAF_DIRECT, CAF_FFT = 0, 1, 2
-DOPPLER_AUTO, DOPPLER_ROCFFT, DOPPLER_FUSED = 0, 1, 2
+DOPPLER_AUTO, DOPPLER_ROCFFT = 0, 1
+COMM_ID_BYTES = 128
 
 
 class PrcoreError(RuntimeError):
@@ -101,6 +102,11 @@ _SIGNATURES = {
                             C.c_void_p]),
     "prc_frequency_shift": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                       C.c_double, C.c_void_p]),
+    "prc_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "prc_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_int32]),
+    "prc_comm_destroy": (C.c_int, [C.c_void_p]),
+    "prc_gather_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_void_p,
+                                    C.c_int32, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -2,8 +2,7 @@
 //
 // Replaces fast_xambg, range_doppler_processing.py:12-90.  The Doppler stage (:89,
 // scipy.fftpack.fft(axis=0) then np.fft.fftshift) is either a rocFFT batched 1-D plan over
-// the contiguous slow-time axis followed by a shift+transpose kernel, or the fused in-LDS
-// radix FFT of caf_fft.hip for power-of-two bin counts.
+// the contiguous slow-time axis followed by one shift+transpose kernel.
 #include "caf_internal.h"
 #include <rocfft/rocfft.h>
 #include <vector>
@@ -104,14 +103,11 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
         delete p;
         return PRC_EUNSUPPORTED;
     }
-    p->doppler = d->doppler;
-    if (p->doppler == PRC_DOPPLER_AUTO)
-        p->doppler = caf_doppler_fused_supported(d->freq_bins) ? PRC_DOPPLER_FUSED : PRC_DOPPLER_ROCFFT;
-    if (p->doppler == PRC_DOPPLER_FUSED && !caf_doppler_fused_supported(d->freq_bins)) {
-        prc_set_error("prc_caf_plan_create: fused Doppler FFT needs a power-of-two freq_bins in "
-                      "[16, 4096], got %d", d->freq_bins);
+    p->doppler = d->doppler == PRC_DOPPLER_AUTO ? PRC_DOPPLER_ROCFFT : d->doppler;
+    if (p->doppler != PRC_DOPPLER_ROCFFT) {
+        prc_set_error("prc_caf_plan_create: unknown Doppler method %d", d->doppler);
         delete p;
-        return PRC_EUNSUPPORTED;
+        return PRC_EINVAL;
     }
     int rc = PRC_OK;
     auto fail = [&](int code) { prc_caf_plan_destroy(p); return code; };
@@ -190,10 +186,9 @@ static int run_segments(prc_caf_plan* p, const void* ref, const void* srv, int64
     a.half = p->half;
     a.range_bins = p->desc.range_bins;
     a.freq_bins = p->desc.freq_bins;
-    a.y_layout = p->doppler == PRC_DOPPLER_FUSED ? PRC_Y_JK : PRC_Y_KJ;
+    a.y_layout = PRC_Y_KJ;
     if (p->method == PRC_CAF_FFT) {
         // the FFT kernel writes whole rows y[j][0..R] (coalesced); rocFFT wants j contiguous
-        if (p->doppler == PRC_DOPPLER_FUSED) return caf_launch_fft(a, nframes, stream);
         a.y = p->d_y2;
         a.y_layout = PRC_Y_JK;
         int rc = caf_launch_fft(a, nframes, stream);
@@ -206,8 +201,6 @@ static int run_segments(prc_caf_plan* p, const void* ref, const void* srv, int64
 static int run_doppler(prc_caf_plan* p, void* out, int nframes, hipStream_t stream) {
     PRC_REQUIRE(out, PRC_EINVAL, "prc_caf_execute: null output");
     const int F = p->desc.freq_bins, cols = p->desc.range_bins + 1;
-    if (p->doppler == PRC_DOPPLER_FUSED)
-        return caf_launch_doppler_fused(p->d_y, (float2*)out, F, p->desc.range_bins, nframes, stream);
     // rocFFT: the plan is batched for max_frames; transforming the unused tail is harmless
     // (it lives in the plan's own buffer) and keeps one plan per shape.
     rocfft_status st = rocfft_execution_info_set_stream(p->info, stream);

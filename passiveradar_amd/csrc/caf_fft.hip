@@ -261,9 +261,3 @@ int caf_launch_transpose_jk_kj(const float2* src, float2* dst, int freq_bins, in
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }
-
-bool caf_doppler_fused_supported(int) { return false; }
-int caf_launch_doppler_fused(const float2*, float2*, int, int, int, hipStream_t) {
-    prc_set_error("fused Doppler FFT not built");
-    return PRC_EUNSUPPORTED;
-}

@@ -3,7 +3,7 @@
 #include "common.h"
 
 // Slow-time buffer layouts written by the segment kernels and read by the Doppler stage.
-enum { PRC_Y_JK = 0,   // y[frame][j][k]   (k contiguous)  -> fused Doppler kernel
+enum { PRC_Y_JK = 0,   // y[frame][j][k]   (k contiguous)  -> written row-wise by the FFT segment kernel
        PRC_Y_KJ = 1 }; // y[frame][k][j]   (j contiguous)  -> rocFFT batched plan
 
 struct CafSegArgs {
@@ -36,8 +36,5 @@ __device__ __forceinline__ void caf_store_y(const CafSegArgs& a, int frame, int6
 int caf_launch_direct(const CafSegArgs& a, int nframes, hipStream_t stream);
 int caf_launch_fft(const CafSegArgs& a, int nframes, hipStream_t stream);
 bool caf_fft_supported(int64_t n, int range_bins, int freq_bins, int ntaps_is_boxcar);
-int caf_launch_doppler_fused(const float2* y, float2* out, int freq_bins, int range_bins,
-                             int nframes, hipStream_t stream);
-bool caf_doppler_fused_supported(int freq_bins);
 int caf_launch_transpose_jk_kj(const float2* src, float2* dst, int freq_bins, int cols, int nframes,
                                hipStream_t stream);

@@ -1,0 +1,167 @@
+// Frame gather over xGMI: the one collective of the path (SURVEY 8e, C2 of 2.3).
+//
+// The reference assembles the per-chunk maps into one (F, R+1, nframes) array through dask's
+// da.store / to_zarr (main.py:213,224).  With CPI frames sharded over the GPUs of a node, the
+// counterpart is a gather of every rank's contiguous block of [frames][F][R+1] complex64 maps to
+// one root: a group of RCCL point-to-point transfers (one ncclRecv per peer on the root, one
+// ncclSend on every other rank), each riding its own xGMI link; there is no reduction and no ring.
+// Blocks may be ragged (strong scaling of 1199 frames over 8 ranks gives 7 x 150 + 149).
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): a single-GPU host never needs it, and inside
+// a process that already carries PyTorch-ROCm's copy (same SONAME) the loader hands back that copy,
+// so there is exactly one RCCL per process.
+#include "common.h"
+#include <dlfcn.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+typedef struct prc_nccl_comm* nccl_comm_t;
+struct nccl_unique_id { char internal[PRC_COMM_ID_BYTES]; };
+typedef int nccl_result_t;                    // ncclSuccess == 0
+constexpr int NCCL_FLOAT32 = 7;               // ncclFloat32 of rccl.h
+
+struct RcclApi {
+    void* handle = nullptr;
+    nccl_result_t (*GetUniqueId)(nccl_unique_id*) = nullptr;
+    nccl_result_t (*CommInitRank)(nccl_comm_t*, int, nccl_unique_id, int) = nullptr;
+    nccl_result_t (*CommDestroy)(nccl_comm_t) = nullptr;
+    nccl_result_t (*GroupStart)() = nullptr;
+    nccl_result_t (*GroupEnd)() = nullptr;
+    nccl_result_t (*Send)(const void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    nccl_result_t (*Recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(nccl_result_t) = nullptr;
+};
+
+RcclApi g_rccl;
+std::mutex g_rccl_mtx;
+
+int rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mtx);
+    if (g_rccl.handle) return PRC_OK;
+    const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    for (const char* nm : names) {
+        h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    PRC_REQUIRE(h, PRC_EUNSUPPORTED, "RCCL not found (dlopen librccl.so.1): %s", dlerror());
+    RcclApi api;
+    api.handle = h;
+#define PRC_RCCL_SYM(field, name)                                                        \
+    *(void**)(&api.field) = dlsym(h, name);                                              \
+    PRC_REQUIRE(api.field, PRC_EUNSUPPORTED, "RCCL symbol %s missing", name)
+    PRC_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    PRC_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    PRC_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    PRC_RCCL_SYM(GroupStart, "ncclGroupStart");
+    PRC_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    PRC_RCCL_SYM(Send, "ncclSend");
+    PRC_RCCL_SYM(Recv, "ncclRecv");
+    PRC_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef PRC_RCCL_SYM
+    g_rccl = api;
+    return PRC_OK;
+}
+
+#define PRC_RCCL(call)                                                                   \
+    do {                                                                                 \
+        nccl_result_t r__ = (call);                                                      \
+        if (r__ != 0) {                                                                  \
+            prc_set_error("%s failed: %s", #call, g_rccl.GetErrorString(r__));           \
+            return PRC_EHIP;                                                             \
+        }                                                                                \
+    } while (0)
+
+}  // namespace
+
+struct prc_comm {
+    nccl_comm_t comm = nullptr;
+    int rank = 0, world = 1;
+    std::mutex mtx;
+};
+
+extern "C" int prc_comm_unique_id(void* id_host) {
+    PRC_REQUIRE(id_host, PRC_EINVAL, "prc_comm_unique_id: null argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    nccl_unique_id id;
+    PRC_RCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id_host, id.internal, PRC_COMM_ID_BYTES);
+    return PRC_OK;
+}
+
+extern "C" int prc_comm_create(prc_comm** comm, const void* id_host, int32_t rank, int32_t world) {
+    PRC_REQUIRE(comm && id_host, PRC_EINVAL, "prc_comm_create: null argument");
+    PRC_REQUIRE(world >= 1 && rank >= 0 && rank < world, PRC_EINVAL,
+                "prc_comm_create: rank %d outside a world of %d", rank, world);
+    int rc = rccl_load();
+    if (rc) return rc;
+    nccl_unique_id id;
+    memcpy(id.internal, id_host, PRC_COMM_ID_BYTES);
+    prc_comm* c = new prc_comm();
+    c->rank = rank;
+    c->world = world;
+    nccl_result_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    if (r != 0) {
+        prc_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r));
+        delete c;
+        return PRC_EHIP;
+    }
+    *comm = c;
+    return PRC_OK;
+}
+
+extern "C" int prc_comm_destroy(prc_comm* c) {
+    if (!c) return PRC_OK;
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+    return PRC_OK;
+}
+
+extern "C" int prc_gather_frames(prc_comm* c, const void* send, const int64_t* frames_per_rank_host,
+                                 int64_t frame_elems, void* recv, int32_t root, void* stream_) {
+    PRC_REQUIRE(c && frames_per_rank_host, PRC_EINVAL, "prc_gather_frames: null argument");
+    PRC_REQUIRE(frame_elems > 0 && root >= 0 && root < c->world, PRC_EINVAL,
+                "prc_gather_frames: bad frame size or root %d", root);
+    hipStream_t stream = (hipStream_t)stream_;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    const int64_t mine = frames_per_rank_host[c->rank];
+    PRC_REQUIRE(mine >= 0 && (mine == 0 || send), PRC_EINVAL, "prc_gather_frames: null send block");
+    const size_t floats_per_frame = (size_t)frame_elems * 2;          // complex64 travels as float pairs
+    if (c->rank != root) {
+        if (mine > 0)
+            PRC_RCCL(g_rccl.Send(send, (size_t)mine * floats_per_frame, NCCL_FLOAT32, root, c->comm, stream));
+        return PRC_OK;
+    }
+    PRC_REQUIRE(recv, PRC_EINVAL, "prc_gather_frames: null receive buffer on the root");
+    float* dst = (float*)recv;
+    int64_t first = 0;
+    for (int r = 0; r < c->world; ++r) {
+        PRC_REQUIRE(frames_per_rank_host[r] >= 0, PRC_EINVAL, "prc_gather_frames: negative block size");
+        if (r == root) break;
+        first += frames_per_rank_host[r];
+    }
+    // the root's own block: a device copy on the same stream (no transfer through RCCL)
+    if (mine > 0 && (const void*)(dst + (size_t)first * floats_per_frame) != send)
+        PRC_HIP(hipMemcpyAsync(dst + (size_t)first * floats_per_frame, send,
+                               (size_t)mine * floats_per_frame * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    if (c->world == 1) return PRC_OK;
+    PRC_RCCL(g_rccl.GroupStart());
+    int64_t off = 0;
+    nccl_result_t bad = 0;
+    for (int r = 0; r < c->world; ++r) {
+        const int64_t cnt = frames_per_rank_host[r];
+        if (r != root && cnt > 0 && bad == 0)
+            bad = g_rccl.Recv(dst + (size_t)off * floats_per_frame, (size_t)cnt * floats_per_frame, NCCL_FLOAT32, r,
+                              c->comm, stream);
+        off += cnt;
+    }
+    nccl_result_t end = g_rccl.GroupEnd();
+    if (bad != 0 || end != 0) {
+        prc_set_error("prc_gather_frames: RCCL receive group failed: %s", g_rccl.GetErrorString(bad ? bad : end));
+        return PRC_EHIP;
+    }
+    return PRC_OK;
+}

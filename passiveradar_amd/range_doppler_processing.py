@@ -21,7 +21,7 @@ _DEFAULTS = {"caf": _lib.CAF_AUTO, "doppler": _lib.DOPPLER_AUTO}
 
 
 def set_default_methods(caf=None, doppler=None):
-    """caf: 0 auto | 1 direct | 2 fft;  doppler: 0 auto | 1 rocfft | 2 fused."""
+    """caf: 0 auto | 1 direct | 2 fft;  doppler: 0 auto | 1 rocfft."""
     if caf is not None:
         _DEFAULTS["caf"] = int(caf)
     if doppler is not None:

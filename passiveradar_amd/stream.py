@@ -20,7 +20,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-__all__ = ["Shard", "plan_shard", "gather_frames", "HipBackend", "StreamProcessor"]
+__all__ = ["Shard", "plan_shard", "shard_sizes", "gather_frames", "FrameComm", "HipBackend", "StreamProcessor"]
 
 
 @dataclass(frozen=True)
@@ -57,43 +57,153 @@ def plan_shard(nchunks, rank=0, world=1):
     return Shard(rank, world, nchunks, lo, hi, max(lo - 1, 0), min(hi + 1, nchunks))
 
 
-_gather_buffers = {}
+class FrameComm:
+    """prc_comm of include/prcore.h: the RCCL communicator behind prc_gather_frames, one per process
+    (one process per GPU).  The 128-byte id is made on rank 0 and shipped to the other ranks through
+    whatever side channel the host has; ``from_torch_distributed`` uses the already initialised
+    torch.distributed group for that (object broadcast) and nothing else."""
+
+    def __init__(self, rank, world, id_bytes):
+        import ctypes as C
+        from . import _lib
+        self.rank, self.world = int(rank), int(world)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(id_bytes), _lib.COMM_ID_BYTES)
+        _lib.check(_lib.lib().prc_comm_create(C.byref(h), buf, self.rank, self.world))
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(_lib.lib().prc_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_torch_distributed(cls, group=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, box[0])
+
+    def gather(self, send, frames_per_rank, frame_elems, recv, root=0, stream=None):
+        """enqueue prc_gather_frames on ``stream`` (device pointers / tensors; recv only on the root)"""
+        import ctypes as C
+        from . import _lib
+        from .engine import _ptr
+        cnt = (C.c_int64 * self.world)(*[int(c) for c in frames_per_rank])
+        _lib.check(_lib.lib().prc_gather_frames(self._h, _ptr(send), cnt, int(frame_elems), _ptr(recv), int(root),
+                                                stream))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            from . import _lib
+            _lib.lib().prc_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-def gather_frames(local, shard, group=None, dst=0, async_op=False):
-    """Gather per-rank frame blocks [m_r][F][R+1] (torch tensors, complex64) to rank ``dst``.
-    Returns the full [nchunks][F][R+1] tensor on dst, None elsewhere.  ONE collective; complex
-    tensors travel as float pairs (RCCL has no complex dtype) without a staging copy when the shard
-    is full-size, and land directly in slices of one preallocated result buffer on dst.
+class _StreamWork:
+    """``work.wait()`` for a gather that was enqueued on a HIP stream (the C-ABI path has no work handle)"""
 
-    async_op=True returns ``(result_or_None, work)``: the gather runs on the communication stream
-    while the caller computes the next batch; ``work.wait()`` before touching the result."""
+    def __init__(self, event, keep):
+        self.event, self.keep = event, keep
+
+    def wait(self):
+        self.event.synchronize()
+        self.keep = None
+
+
+def shard_sizes(shard):
+    """frames owned by every rank of ``shard``'s world (contiguous ceil(nchunks/world) blocks, plan_shard)"""
+    per = -(-shard.nchunks // shard.world)
+    return [max(min((r + 1) * per, shard.nchunks) - min(r * per, shard.nchunks), 0) for r in range(shard.world)]
+
+
+def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, comm=None, stream=None):
+    """Gather per-rank frame blocks [m_r][F][R+1] (torch tensors, complex64) to global rank ``dst``.
+    Returns the full [nchunks][F][R+1] tensor on dst, None elsewhere.  ONE collective.
+
+    comm: a FrameComm -> prc_gather_frames (RCCL point-to-point group through the C ABI, ragged blocks
+    land at their place, nothing is padded); it is enqueued on ``stream`` (a torch stream, default the
+    current one).  comm=None -> torch.distributed.gather on ``group`` (gloo in the CPU tests; complex
+    tensors travel as float pairs, blocks padded to ceil(nchunks/world) frames).
+
+    out: optional preallocated [nchunks][F][R+1] complex64 result on dst -- callers that gather every
+    step pass their own (ping-pong) buffers; by default a fresh tensor is returned, never a cached one.
+
+    async_op=True returns ``(result_or_None, work)``: ``work.wait()`` before touching the result (and
+    before reusing ``local``)."""
     import torch
     import torch.distributed as dist
     if shard.world == 1:
         return (local, None) if async_op else local
-    per = -(-shard.nchunks // shard.world)
     F, cols = local.shape[1], local.shape[2]
+    on_dst = dist.get_rank() == dst                     # global rank, also for sub-groups
+    res = None
+    if on_dst:
+        res = out if out is not None else torch.empty((shard.nchunks, F, cols), dtype=torch.complex64,
+                                                       device=local.device)
+        assert tuple(res.shape) == (shard.nchunks, F, cols) and res.is_contiguous()
+    if comm is not None:
+        import ctypes
+        st = torch.cuda.current_stream(local.device) if stream is None else stream
+        send = local if local.is_contiguous() else local.contiguous()
+        with torch.cuda.device(local.device):
+            comm.gather(send, shard_sizes(shard), F * cols, res, dst, ctypes.c_void_p(st.cuda_stream))
+        if not async_op:
+            st.synchronize()
+            return res
+        ev = torch.cuda.Event()
+        ev.record(st)
+        return res, _StreamWork(ev, send)
+    per = -(-shard.nchunks // shard.world)
     if shard.nframes == per and local.is_contiguous():
         send = torch.view_as_real(local)
     else:
         send = torch.zeros((per, F, cols, 2), dtype=torch.float32, device=local.device)
         if shard.nframes:
             send[:shard.nframes] = torch.view_as_real(local)
-    if dist.get_rank(group) == dst:
-        key = (shard.world, per, F, cols, str(local.device))
-        full = _gather_buffers.get(key)
-        if full is None or async_op:
-            # a fresh buffer per in-flight async gather; a cached one for the blocking form
-            full = torch.empty((shard.world * per, F, cols, 2), dtype=torch.float32, device=local.device)
-            if not async_op:
-                _gather_buffers[key] = full
-        recv = [full[r * per:(r + 1) * per] for r in range(shard.world)]
+    if on_dst:
+        resr = torch.view_as_real(res)
+        recv, tail = [], None
+        for r in range(shard.world):
+            lo, hi = r * per, (r + 1) * per
+            if hi <= shard.nchunks:
+                recv.append(resr[lo:hi])                        # lands in place
+            else:                                               # ragged / empty last blocks: staged
+                tmp = torch.empty((per, F, cols, 2), dtype=torch.float32, device=local.device)
+                recv.append(tmp)
+                tail = (tail or []) + [(lo, tmp)]
         work = dist.gather(send, recv, dst=dst, group=group, async_op=async_op)
-        res = torch.view_as_complex(full)[:shard.nchunks]
-        return (res, work) if async_op else res
+
+        def finish():
+            for lo, tmp in tail or ():
+                m = max(min(shard.nchunks - lo, per), 0)
+                if m:
+                    resr[lo:lo + m].copy_(tmp[:m])
+        if not async_op:
+            finish()
+            return res
+        return res, _TorchWork(work, finish)
     work = dist.gather(send, None, dst=dst, group=group, async_op=async_op)
     return (None, work) if async_op else None
+
+
+class _TorchWork:
+    def __init__(self, work, finish):
+        self.work, self.finish = work, finish
+
+    def wait(self):
+        self.work.wait()
+        self.finish()
 
 
 class HipBackend:
@@ -224,17 +334,19 @@ class HipBackend:
                                  self.window, self._stream() if stream is None else stream)
         return out
 
-    def run(self, ref_pad, srv_pad, nlocal, offsets_first, nframes):
+    def run(self, ref_pad, srv_pad, nlocal, offsets_first, nframes, out=None):
         """clean + frames for one resident shard.  With ``overlap`` the LS chain runs sub-batch by
         sub-batch on one stream and the CAF of every frame whose three chunks are already clean
-        follows on a second stream (frame j needs local chunk j + offsets_first/C + 1)."""
+        follows on a second stream (frame j needs local chunk j + offsets_first/C + 1).
+        out: optional preallocated [>= nframes][F][R+1] complex64 tensor for the maps."""
         if not self.overlap or nlocal <= self.sub:
             clean = self.clean(ref_pad, srv_pad, nlocal)
-            return self.frames(ref_pad, clean, offsets_first, nframes)
+            return self.frames(ref_pad, clean, offsets_first, nframes, out)
         import ctypes
         torch = self.torch
         clean = self._clean_target(srv_pad)
-        out = torch.empty((nframes, self.F, self.R + 1), dtype=torch.complex64, device=self.device)
+        if out is None:
+            out = torch.empty((nframes, self.F, self.R + 1), dtype=torch.complex64, device=self.device)
         main = torch.cuda.current_stream()
         self.s_ls.wait_stream(main)
         self.s_caf.wait_stream(main)
@@ -260,9 +372,10 @@ class HipBackend:
 class StreamProcessor:
     """main.py:169-194 for an in-memory IF stream; ``backend`` does the per-shard compute."""
 
-    def __init__(self, backend, rank=0, world=1, group=None):
+    def __init__(self, backend, rank=0, world=1, group=None, comm=None):
         self.backend = backend
         self.rank, self.world, self.group = rank, world, group
+        self.comm = comm            # FrameComm: gather through prc_gather_frames instead of torch.distributed
 
     @classmethod
     def from_config(cls, config, **kw):
@@ -296,7 +409,7 @@ class StreamProcessor:
         frames, sh = self.process_local(ref, srv)
         if self.world == 1 or not gather:
             return frames
-        return gather_frames(frames, sh, self.group)
+        return gather_frames(frames, sh, self.group, comm=self.comm)
 
     def process_raw(self, raw_ref, raw_srv, config, gather=True):
         """main.py:105-194 from the raw interleaved recordings: front end per channel (device), then

@@ -63,3 +63,90 @@ def test_sharded_stream_matches_golden(world):
     assert full.shape == ref.shape
     assert rel_err(full, ref) < 1e-5
     assert sh0[0] == 0 and sh0[2] == 0
+
+
+class _CheapBackend:
+    """A stand-in backend whose per-chunk 'canceller' and per-frame 'map' are cheap but sensitive to exactly
+    the things sharding can get wrong: which chunk a sample belongs to (per-chunk statistics, like the per-chunk
+    LS taps) and which three chunks a frame touches (zeros beyond the stream ends)."""
+
+    def __init__(self, C, F, cols):
+        self.C, self.cpi, self.F, self.R = C, 2 * C, F, cols - 1
+        self.device = "cpu"
+
+    def padded(self, chunks):
+        x = np.asarray(chunks, dtype=np.complex64)
+        z = np.zeros(self.C // 2, np.complex64)
+        return np.concatenate((z, x, z))
+
+    def clean(self, ref_pad, srv_pad, nlocal):
+        C, h = self.C, self.C // 2
+        out = np.zeros_like(srv_pad)
+        for c in range(nlocal):
+            sl = slice(h + c * C, h + (c + 1) * C)
+            out[sl] = srv_pad[sl] - srv_pad[sl].mean() * ref_pad[sl]          # per-chunk coefficient
+        return out
+
+    def frames(self, ref_pad, clean_pad, first, nframes):
+        k = np.arange(self.F * (self.R + 1)).reshape(self.F, self.R + 1)
+        fr = []
+        for i in range(nframes):
+            a = ref_pad[first + i * self.C:first + i * self.C + self.cpi]
+            s = clean_pad[first + i * self.C:first + i * self.C + self.cpi]
+            w = np.arange(1, self.cpi + 1)
+            fr.append(((a * np.conj(s) * w).sum() * np.exp(1j * 0.01 * k)).astype(np.complex64))
+        return torch.from_numpy(np.stack(fr))
+
+
+def _stream_1199(C=8):
+    rng = np.random.default_rng(1199)
+    n = 1199 * C
+    ref = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    srv = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) + ref
+    return ref, srv
+
+
+def _worker_1199(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from passiveradar_amd.stream import StreamProcessor, gather_frames, plan_shard, shard_sizes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ref, srv = _stream_1199()
+    sp = StreamProcessor(_CheapBackend(8, 4, 3), rank, world)
+    frames, sh = sp.process_local(ref, srv)
+    assert sh == plan_shard(1199, rank, world) and frames.shape[0] == shard_sizes(sh)[rank]
+    full = sp.process(ref, srv)
+    # two gathers into caller-owned buffers (what bench.py does every step): results stay distinct
+    outs = [torch.empty((1199, 4, 3), dtype=torch.complex64) if rank == 0 else None for _ in range(2)]
+    r0, w0 = gather_frames(frames, sh, async_op=True, out=outs[0])
+    r1, w1 = gather_frames(frames * 2, sh, async_op=True, out=outs[1])
+    w0.wait(); w1.wait()
+    if rank == 0:
+        assert r0 is outs[0] and torch.equal(r0, full) and torch.equal(r1, full * 2)
+        q.put(full.numpy())
+    else:
+        assert full is None and r0 is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfg4_stream_of_1199_frames_sharded_over_8_ranks():
+    """BASELINE config 4's shape of work: 1199 frames (600 s of cfg-2 IQ), contiguous shards over 8 ranks
+    (7 x 150 + 149), halo chunks re-filtered locally, one gather -- equals the unsharded pass."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_1199, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    from passiveradar_amd.stream import StreamProcessor
+    ref, srv = _stream_1199()
+    single = StreamProcessor(_CheapBackend(8, 4, 3)).process(ref, srv).numpy()
+    assert full.shape == (1199, 4, 3) and np.array_equal(full, single)

@@ -198,3 +198,60 @@ def test_cfg1_pipeline_against_reference_output():
     a, s = scene.make_stream(3, n // 2, fs, R, int(g["seed"]))
     X = StreamProcessor(HipBackend(n, R, F, fs, batch=3)).process(a, s)[int(g["frame_index"])].cpu().numpy()
     assert X.shape == g["out"].shape and rel_err(X, g["out"]) < 1e-4
+
+
+def test_prc_gather_frames_single_rank():
+    """prc_comm_* / prc_gather_frames through the C ABI on one GPU: a world of one (RCCL is loaded, the
+    communicator is created, the root's own block is a device copy into its slot); ragged and empty blocks
+    are accepted.  The multi-rank pattern (one ncclRecv per peer) is covered on CPU by the gloo tests of the
+    same Shard arithmetic."""
+    import ctypes
+    import torch
+    from passiveradar_amd.stream import FrameComm
+    comm = FrameComm(0, 1, FrameComm.unique_id())
+    F, cols = 16, 9
+    blk = torch.randn((5, F, cols), dtype=torch.complex64, device="cuda")
+    out = torch.zeros((5, F, cols), dtype=torch.complex64, device="cuda")
+    st = torch.cuda.current_stream()
+    comm.gather(blk, [5], F * cols, out, 0, ctypes.c_void_p(st.cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(out, blk)
+    # in place: the block already sits in its slot of the receive buffer
+    comm.gather(out, [5], F * cols, out, 0, ctypes.c_void_p(st.cuda_stream))
+    # an empty block
+    comm.gather(None, [0], F * cols, out, 0, ctypes.c_void_p(st.cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(out, blk)
+    comm.close()
+
+
+def test_four_illuminator_step_equals_four_single_cafs():
+    """BASELINE config 5's structure (q = 4096, R = 2048: the same segment / lag-block shape as the full-size
+    2048 x 2048 surface, fewer Doppler rows): four reference channels against ONE surveillance channel over a
+    batch of overlapped frames == four separate fast_xambg calls per frame (oracle-checked on one of them)."""
+    import torch
+    from scipy.signal import get_window
+    from passiveradar_amd.range_doppler_processing import fast_xambg
+    from passiveradar_amd.stream import HipBackend
+    n, R, F, fs, nfr = 1 << 17, 2048, 32, 2.0e7, 3
+    C = n // 2
+    rng = np.random.default_rng(55)
+    refs = [(rng.standard_normal(nfr * C) + 1j * rng.standard_normal(nfr * C)).astype(np.complex64) for _ in range(4)]
+    srv = sum(np.roll(r, 100 * (i + 1)) * (0.5 + 0.1 * i) for i, r in enumerate(refs)).astype(np.complex64)
+    be = HipBackend(n, R, F, fs, clutter=None, batch=nfr)
+    srv_pad = be.padded(srv)
+    w = get_window(("kaiser", 5.0), n)
+    pad = np.zeros(C // 2, np.complex64)
+    sp = np.concatenate((pad, srv, pad))
+    for i, r in enumerate(refs):
+        got = be.run(be.padded(r), srv_pad, nfr, 0, nfr).cpu().numpy()
+        rp = np.concatenate((pad, r, pad))
+        for f in range(nfr):
+            one = fast_xambg(rp[f * C:f * C + n], sp[f * C:f * C + n], R, F, n, w)[:, :, 0]
+            assert rel_err(got[f], one) < 1e-6
+        # the echo of illuminator i sits at delay 100 (i+1), zero Doppler
+        mid = np.abs(got[1])
+        assert np.unravel_index(mid.argmax(), mid.shape) == (F // 2, R - 100 * (i + 1))
+    from oracle import np_oracle as O
+    exp = O.fast_xambg(rp[C:C + n], sp[C:C + n], R, F, n, w)[:, :, 0]
+    assert rel_err(got[1], exp) < 1e-4

@@ -93,6 +93,17 @@ def test_plan_shard_covers_every_frame_once(nchunks, world):
     assert seen == list(range(nchunks))
 
 
+def test_shard_sizes_of_the_600_s_stream():
+    """config 4: 1199 frames over 8 GPUs = 7 x 150 + 149; blocks sum to the stream whatever the world size"""
+    from passiveradar_amd.stream import shard_sizes
+    assert shard_sizes(plan_shard(1199, 0, 8)) == [150] * 7 + [149]
+    for world in (1, 2, 3, 5, 8, 16):
+        for nchunks in (1, 7, 1199):
+            sz = shard_sizes(plan_shard(nchunks, 0, world))
+            assert sum(sz) == nchunks and len(sz) == world
+            assert sz == [plan_shard(nchunks, r, world).nframes for r in range(world)]
+
+
 def test_shape_errors_are_raised_before_any_device_call():
     from passiveradar_amd.clutter_removal import LS_Filter, LS_Filter_Multiple, LS_Filter_Toeplitz
     from passiveradar_amd.range_doppler_processing import fast_xambg
