@@ -46,6 +46,7 @@ int prc_version(void);
 const char* prc_last_error(void);
 int prc_device_count(int* count);
 int prc_set_device(int device);
+int prc_get_device(int* device);       /* the calling thread's current HIP device */
 /* Device-memory helpers for hosts that do not bring their own allocator (the NumPy-facing
  * drop-in functions use these; torch-based callers pass tensor.data_ptr() instead). */
 int prc_malloc(void** dptr, size_t bytes);

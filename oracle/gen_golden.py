@@ -361,6 +361,60 @@ def pipeline_cfg2_case():
          cleaned_sub=cleaned[::101].astype(np.complex64), out=out[:, :, 0].astype(np.complex64))
 
 
+def pipeline_cfg2_c128_case():
+    """BASELINE config 2 end to end with the reference's own functions fed complex128 inputs: its
+    scipy.signal.correlate / np.convolve then sum the 1.2 M-term correlations in double (clutter_removal.py:142-155,
+    signal_utils.py:29-32), which removes the float32 summation noise that sits on the zero-Doppler ridge of
+    pipeline_cfg2.npz.  Same scene, same geometry (three hop chunks, the middle overlapped frame)."""
+    print("config-2 pipeline frame, complex128 inputs to the reference (LS x5 + CAF at full size)")
+    n, R, F, fs = 2400000, 256, 512, 2.4e6
+    C = n // 2
+    a, s = scene.make_stream(3, C, fs, R, scene.scene_seed(4))
+    a = a.astype(np.complex128)
+    s = s.astype(np.complex128)
+    t0 = time.time()
+    cleaned = np.concatenate([
+        ref_cr.LS_Filter_Multiple(a[i * C:(i + 1) * C], s[i * C:(i + 1) * C], R, fs, [0, 1, -1, 2, -2])
+        for i in range(3)])
+    print(f"  LS_Filter_Multiple x3 chunks {time.time() - t0:.1f}s  dtype {cleaned.dtype}")
+    pad = np.zeros(n // 4)
+    ap = np.concatenate((pad, a, pad))
+    sp = np.concatenate((pad, cleaned, pad))
+    w = signal.get_window(("kaiser", 5.0), n)
+    t0 = time.time()
+    with no_root_finding():
+        out = ref_rd.fast_xambg(ap[C:C + n], sp[C:C + n], R, F, n, w)
+    print(f"  fast_xambg {time.time() - t0:.1f}s")
+    save("pipeline_cfg2_c128", seed=scene.scene_seed(4), N=n, R=R, F=F, fs=fs, frame_index=1,
+         cleaned_sub=cleaned[::101].astype(np.complex64), out=out[:, :, 0].astype(np.complex64))
+
+
+def ls_wide_cases():
+    """LS_Filter_Multiple with Doppler bins far from zero (|2 pi f/Fs| * peek up to ~0.4 rad: the reference accepts
+    any bin list, clutter_removal.py:178-187) and the LS filters at the config-3 tap count T = 1034."""
+    print("LS filters: large Doppler bins, T = 1034")
+    n, L = 12000, 30
+    a, s = scene.make_scene(n, 1.0e4, L, scene.scene_seed(94))
+    save("ls_multiple_bin50", ref=a, srv=s, L=L, fs=1.0e4, bins=np.array([0.0, 50.0]),
+         out=ref_cr.LS_Filter_Multiple(a, s, L, 1.0e4, [0, 50]))
+    save("ls_multiple_kHz", ref=a, srv=s, L=L, fs=262184.87, bins=np.array([0.0, 1500.0, -1700.0, 40.0]),
+         out=ref_cr.LS_Filter_Multiple(a, s, L, 262184.87, [0, 1500, -1700, 40]))
+    n, L = 40000, 1024
+    a, s = scene.make_scene(n, 1.0e7, L, scene.scene_seed(31))
+    t0 = time.time()
+    o, t = ref_cr.LS_Filter_Toeplitz(a, s, L, return_filter=True)
+    om = ref_cr.LS_Filter_Multiple(a, s, L, 1.0e7, [0, 1, -1])
+    print(f"  T=1034 Toeplitz + Multiple {time.time() - t0:.1f}s")
+    save("ls_t1034", seed=scene.scene_seed(31), N=n, L=L, fs=1.0e7, bins=np.array([0.0, 1.0, -1.0]),
+         out=o.astype(np.complex64), taps=t, out_multiple=om.astype(np.complex64))
+    n2 = 12288
+    a2, s2 = scene.make_scene(n2, 1.0e7, L, scene.scene_seed(32))
+    t0 = time.time()
+    o2, t2 = ref_cr.LS_Filter(a2, s2, L, return_filter=True)
+    print(f"  T=1034 LS_Filter (N x T matrix of {n2 * 1034 * 8 / 1e6:.0f} MB) {time.time() - t0:.1f}s")
+    save("ls_direct_t1034", seed=scene.scene_seed(32), N=n2, L=L, fs=1.0e7, reg=1.0, out=o2, taps=t2)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also generate the cfg1/2/3 CAF goldens (minutes)")
@@ -383,5 +437,9 @@ if __name__ == "__main__":
         cfar_case()
         offset_case()
         ls_cfg1_case()
+        ls_wide_cases()
     if args.big or args.only_big:
         big_cases()
+        pipeline_cfg1_case()
+        pipeline_cfg2_case()
+        pipeline_cfg2_c128_case()

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "prc_last_error": (C.c_char_p, []),
     "prc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "prc_set_device": (C.c_int, [C.c_int]),
+    "prc_get_device": (C.c_int, [C.POINTER(C.c_int)]),
     "prc_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "prc_free": (C.c_int, [C.c_void_p]),
     "prc_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -177,6 +178,12 @@ def device_count():
     return n.value if rc == PRC_OK else 0
 
 
+def current_device():
+    """the calling thread's current HIP device index (-1 without a GPU)"""
+    d = C.c_int(-1)
+    return d.value if lib().prc_get_device(C.byref(d)) == PRC_OK else -1
+
+
 def require_gpu():
     if device_count() < 1:
         raise PrcoreError(PRC_EHIP, "no ROCm device visible: " +
@@ -226,6 +233,7 @@ def is_device_tensor(x):
     return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
 
 
-def torch_stream_ptr():
+def torch_stream_ptr(device=None):
+    """hipStream_t of torch's current stream on ``device`` (default: the current device)"""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -6,6 +6,7 @@
 // (j + (fw-1)/2 - b) mod W]  (asymmetric for even fw -- reproduced, not "fixed").
 // One pass for the mean (block partials), one pass for the box sums from an LDS tile with wrap halo.
 #include "common.h"
+#include <vector>
 
 #define CF_TX 32
 #define CF_TY 8
@@ -74,23 +75,40 @@ extern "C" int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int3
     PRC_REQUIRE(fw * fw != gw * gw, PRC_EINVAL, "prc_cfar2d: fw^2 == gw^2 divides by zero (as in the reference)");
     hipStream_t stream = (hipStream_t)stream_;
     const int np = 64;
-    // per host thread scratch for the |X| partial sums, grown on demand and kept (stream-ordered pool allocation
-    // -- hipMallocAsync / hipFreeAsync -- intermittently handed the block to a later call while this one's
-    // kernels were still queued: whole maps came back scaled by a wrong mean)
-    struct Scratch { float* p = nullptr; size_t cap = 0; int dev = -1; };
-    static thread_local Scratch sc;
+    // scratch for the |X| partial sums: per host thread AND per (device, stream), grown on demand and kept.  Two
+    // calls from one thread on different streams never share a buffer (the second call's partial-sum kernel could
+    // otherwise overwrite what the first call's cfar_kernel has not read yet); calls on one stream are ordered by
+    // the stream.  (Stream-ordered pool allocation -- hipMallocAsync / hipFreeAsync -- intermittently handed the
+    // block to a later call while this one's kernels were still queued: whole maps came back scaled by a wrong mean.)
+    struct Scratch { float* p = nullptr; size_t cap = 0; int dev = -1; hipStream_t stream = nullptr; };
+    static thread_local std::vector<Scratch> pool;
     int dev = 0;
     PRC_HIP(hipGetDevice(&dev));
     const size_t need = sizeof(float) * (size_t)np * (size_t)nframes;
-    if (sc.dev != dev || sc.cap < need) {
-        if (sc.p) {
+    Scratch* hit = nullptr;
+    for (Scratch& c : pool)
+        if (c.dev == dev && c.stream == stream) { hit = &c; break; }
+    if (!hit) {
+        if (pool.size() >= 16) {                      // a host cycling through many streams: start over
             PRC_HIP(hipDeviceSynchronize());
+            for (Scratch& c : pool) (void)hipFree(c.p);
+            pool.clear();
+        }
+        pool.push_back(Scratch());
+        hit = &pool.back();
+        hit->dev = dev;
+        hit->stream = stream;
+    }
+    Scratch& sc = *hit;
+    if (sc.cap < need) {
+        if (sc.p) {
+            PRC_HIP(hipStreamSynchronize(stream));    // only this stream ever used the block
             (void)hipFree(sc.p);
             sc.p = nullptr;
+            sc.cap = 0;
         }
         PRC_HIP(hipMalloc((void**)&sc.p, need));
         sc.cap = need;
-        sc.dev = dev;
     }
     float* d_partial = sc.p;
     hipLaunchKernelGGL(cfar_abs_partial_kernel, dim3(np, nframes), dim3(256), 0, stream, X, (int64_t)H * W, d_partial);

@@ -740,8 +740,6 @@ static int run_cached_chain(prc_ls_plan* p, const void* ref, const void* srv, in
     int rc;
     {
         const PhaseRamp pr0 = make_ramp(bins[0], sample_rate, 0.0);
-        PRC_REQUIRE(!pr0.enabled || fabs(theta_exact(0)) * (p->desc.peek + 1) <= 0.3, PRC_EUNSUPPORTED,
-                    "prc_ls_execute: |2 pi fc/Fs| * peek too large for the FFT kernels (use method=1)");
         LsFftArgs xa;
         fill_xa(xa, p, ref, stride, cur, cur_stride, nullptr, 0, pr0);
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[0], stream));
@@ -773,8 +771,6 @@ static int run_cached_chain(prc_ls_plan* p, const void* ref, const void* srv, in
         if (has_next) {
             const PhaseRamp prn = make_ramp(bins[ib + 1], sample_rate, 0.0);
             theta_out = theta_exact(ib + 1);
-            PRC_REQUIRE(!prn.enabled || fabs(theta_out) * (p->desc.peek + 1) <= 0.3, PRC_EUNSUPPORTED,
-                        "prc_ls_execute: |2 pi fc/Fs| * peek too large for the FFT kernels (use method=1)");
             xa.has_next = 1;
             xa.rot2 = prn.enabled;
             xa.pr2 = prn;
@@ -840,9 +836,6 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
             if (p->method == 2 && pr.enabled) {
                 PRC_REQUIRE(!p->desc.circular, PRC_EUNSUPPORTED,
                             "prc_ls_execute: Doppler-shifted bins with the circular (LS_Filter) form need method=1");
-                PRC_REQUIRE(fabs(theta) * (p->desc.peek + 1) <= 0.3, PRC_EUNSUPPORTED,
-                            "prc_ls_execute: |2 pi fc/Fs| * peek = %g too large for the FFT kernels (use method=1)",
-                            fabs(theta) * p->desc.peek);
             }
             LsFftArgs xa;
             fill_xa(xa, p, ref, stride, cur, cur_stride, dst, dst_stride, pr);

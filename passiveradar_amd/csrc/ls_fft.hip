@@ -12,8 +12,7 @@
 // r is the peek-rotated, Doppler-rotated reference generated on the fly: one sincosf per lane per
 // piece at the reference's float32 phase (signal_utils.py:24-27) times a per-register constant
 // step e^{j theta 64 r}; the <= peek samples that wrapped around the block end (np.roll at :139)
-// restart the ramp at index 0 and take a 7th-order Taylor phase (|theta*peek| <= 0.3 enforced on
-// the host).  All loads are branch-free (clamped address + select) and issued one FFT ahead of
+// restart the ramp at index 0 and take their own phase theta*index (Taylor for small arguments).  All loads are branch-free (clamped address + select) and issued one FFT ahead of
 // their use, so each loop body is a single straight-line block the scheduler can overlap.
 #include "ls_internal.h"
 #include "fft_wave.h"
@@ -22,13 +21,21 @@ int fftw_device_tables(const float2** out);   // caf_fft.hip
 
 #define LSF_WAVES 4
 
-// exp(j x) for |x| <= 0.3 (error < 2e-9)
+// exp(j x): 7th-order Taylor for |x| <= 0.3 (error < 2e-9, the usual case: Doppler bins of a few Hz), sincosf
+// beyond (bins of kHz at a few hundred kHz of sample rate; only ever reached in the rarely taken wrap branches)
 __device__ __forceinline__ float2 small_rot(float x) {
+    if (fabsf(x) > 0.3f) {
+        float s, c;
+        sincosf(x, &s, &c);
+        return make_float2(c, s);
+    }
     const float x2 = x * x;
     const float c = 1.f + x2 * (-0.5f + x2 * (1.f / 24.f + x2 * (-1.f / 720.f)));
     const float s = x * (1.f + x2 * (-1.f / 6.f + x2 * (1.f / 120.f + x2 * (-1.f / 5040.f))));
     return make_float2(c, s);
 }
+// index of a wrapped sample inside [0, peek]: lanes outside the wrapped run carry zeros, keep their phase argument small
+__device__ __forceinline__ float wrap_index(int k, int peek) { return (float)(k < 0 ? 0 : (k > peek ? peek : k)); }
 
 struct RefSlot {       // one register slot of the rotated reference, before the data arrived
     bool ok;           // slot carries a sample (else zero)
@@ -55,7 +62,7 @@ __device__ __forceinline__ float2 ref_finish(float2 raw, const RefSlot& s, int r
     float2 v = raw;
     if (rot) {
         const float2 cont = cmul(base, step);
-        const float2 wrapped = small_rot(theta32 * (float)s.off);
+        const float2 wrapped = small_rot(theta32 * (float)(s.wr ? s.off : 0));
         v = cmul(v, s.wr ? wrapped : cont);
     }
     return s.ok ? v : make_float2(0.f, 0.f);
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, AUTO ? 1 : 2) void ls_corr_fft_lin_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float2 w = prc_buf_load_c64(rw, voff + 512u * r, 0u);
-                if (a.rot) w = cmul(w, small_rot(a.theta32 * (float)(64 * r + lane - wstart)));
+                if (a.rot) w = cmul(w, small_rot(a.theta32 * wrap_index(64 * r + lane - wstart, peek)));
                 v[r].x += w.x;
                 v[r].y += w.y;
             }
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fir_fft_lin_kernel(LsFft
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float2 w = prc_buf_load_c64(rw, voff + 512u * r, 0u);
-                if (a.rot) w = cmul(w, small_rot(a.theta32 * (float)(64 * r + lane - wstart)));
+                if (a.rot) w = cmul(w, small_rot(a.theta32 * wrap_index(64 * r + lane - wstart, peek)));
                 x[r].x += w.x;
                 x[r].y += w.y;
             }

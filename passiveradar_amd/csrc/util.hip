@@ -27,6 +27,12 @@ extern "C" int prc_set_device(int device) {
     return PRC_OK;
 }
 
+extern "C" int prc_get_device(int* device) {
+    PRC_REQUIRE(device, PRC_EINVAL, "prc_get_device: null argument");
+    PRC_HIP(hipGetDevice(device));
+    return PRC_OK;
+}
+
 extern "C" int prc_malloc(void** dptr, size_t bytes) {
     PRC_REQUIRE(dptr, PRC_EINVAL, "prc_malloc: null argument");
     *dptr = nullptr;

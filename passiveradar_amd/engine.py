@@ -262,7 +262,10 @@ def nlms_execute(ref, srv, out, n, filter_len, mu, peek=10, taps_in=None, taps_o
 _tls = threading.local()
 
 
-def cached_plan(key, factory, limit=8):
+def cached_plan(key, factory, limit=8, stream=None):
+    """One plan per (thread, device, stream, shape key): a plan's workspaces live on the device that was current
+    when it was made, and its single slow-time / tap workspace must not be shared by launches on two streams."""
+    key = (_lib.current_device(), getattr(stream, "value", stream)) + tuple(key)
     cache = getattr(_tls, "plans", None)
     if cache is None:
         cache = _tls.plans = {}
@@ -291,7 +294,12 @@ class Staging:
 
 
 def staging():
-    st = getattr(_tls, "staging", None)
+    """per thread and per device"""
+    per_dev = getattr(_tls, "staging", None)
+    if per_dev is None:
+        per_dev = _tls.staging = {}
+    dev = _lib.current_device()
+    st = per_dev.get(dev)
     if st is None:
-        st = _tls.staging = Staging()
+        st = per_dev[dev] = Staging()
     return st

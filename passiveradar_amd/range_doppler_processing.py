@@ -42,7 +42,7 @@ def _long_taps(q):
     return np.ascontiguousarray(firwin(10 * q + 1, 1.0 / q, window="flattop"), dtype=np.float32)
 
 
-def caf_plan_for(n, rangeBins, freqBins, shortFilt=True, max_frames=1, method=None, doppler=None):
+def caf_plan_for(n, rangeBins, freqBins, shortFilt=True, max_frames=1, method=None, doppler=None, stream=None):
     method = _DEFAULTS["caf"] if method is None else method
     doppler = _DEFAULTS["doppler"] if doppler is None else doppler
     if not shortFilt and method == _lib.CAF_FFT:
@@ -51,7 +51,7 @@ def caf_plan_for(n, rangeBins, freqBins, shortFilt=True, max_frames=1, method=No
     key = ("caf", n, rangeBins, freqBins, bool(shortFilt), max_frames, method, doppler)
     taps = None if shortFilt else _long_taps(q)
     return engine.cached_plan(key, lambda: engine.CafPlan(n, rangeBins, freqBins, max_frames,
-                                                          method, doppler, taps))
+                                                          method, doppler, taps), stream=stream)
 
 
 def fast_xambg(refChannel, srvChannel, rangeBins, freqBins, inputLen=None, window=None,
@@ -74,21 +74,25 @@ def fast_xambg(refChannel, srvChannel, rangeBins, freqBins, inputLen=None, windo
         if window.shape[0] != n:
             raise ValueError(f"operands could not be broadcast together with shapes ({n},) "
                              f"({window.shape[0]},)")
-    plan = caf_plan_for(n, int(rangeBins), int(freqBins), shortFilt)
-
     if _lib.is_device_tensor(refChannel):
         import torch
-        ref = refChannel.to(torch.complex64).contiguous()
-        srv = srvChannel.to(torch.complex64).contiguous()
-        win = None
-        if window is not None:
-            win = window if _lib.is_device_tensor(window) else torch.from_numpy(window).to(ref.device)
-            win = win.to(torch.float32).contiguous()
-        out = torch.empty((int(freqBins), int(rangeBins) + 1, 1), dtype=torch.complex64,
-                          device=ref.device)
-        plan.execute(ref, srv, out, 1, n, n_in, win, stream=_lib.torch_stream_ptr())
+        # everything on the tensors' own device and on torch's current stream THERE (not on whatever device
+        # happens to be current): the plan, its workspaces and the launch
+        with torch.cuda.device(refChannel.device):
+            st = _lib.torch_stream_ptr(refChannel.device)
+            plan = caf_plan_for(n, int(rangeBins), int(freqBins), shortFilt, stream=st)
+            ref = refChannel.to(torch.complex64).contiguous()
+            srv = srvChannel.to(device=ref.device, dtype=torch.complex64).contiguous()
+            win = None
+            if window is not None:
+                win = window if _lib.is_device_tensor(window) else torch.from_numpy(window)
+                win = win.to(device=ref.device, dtype=torch.float32).contiguous()
+            out = torch.empty((int(freqBins), int(rangeBins) + 1, 1), dtype=torch.complex64,
+                              device=ref.device)
+            plan.execute(ref, srv, out, 1, n, n_in, win, stream=st)
         return out
 
+    plan = caf_plan_for(n, int(rangeBins), int(freqBins), shortFilt)
     ref = np.ascontiguousarray(refChannel, dtype=np.complex64)
     srv = np.ascontiguousarray(srvChannel, dtype=np.complex64)   # complex128 srv is narrowed
     st = engine.staging()

@@ -251,7 +251,7 @@ class HipBackend:
 
     def _stream(self):
         from . import _lib
-        return _lib.torch_stream_ptr()
+        return _lib.torch_stream_ptr(self.device)
 
     def padded(self, chunks):
         """[C/2 zeros | chunks | C/2 zeros] complex64 on the device (chunks: 1-D host or device)."""

@@ -21,8 +21,9 @@ def CFAR_2D(X, fw, gw, thresh=None):
         frames = 1 if x.dim() == 2 else x.shape[0]
         H, W = x.shape[-2], x.shape[-1]
         out = torch.empty_like(x)
-        check(lib().prc_cfar2d(x.data_ptr(), H, W, int(fw), int(gw), int(thresh is not None),
-                               float(thresh or 0.0), out.data_ptr(), frames, _lib.torch_stream_ptr()))
+        with torch.cuda.device(x.device):          # launch on the tensor's device and torch's stream there
+            check(lib().prc_cfar2d(x.data_ptr(), H, W, int(fw), int(gw), int(thresh is not None),
+                                   float(thresh or 0.0), out.data_ptr(), frames, _lib.torch_stream_ptr(x.device)))
         return out.bool() if thresh is not None else out
     x = np.ascontiguousarray(X, dtype=np.float32)
     frames = 1 if x.ndim == 2 else x.shape[0]
