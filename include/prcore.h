@@ -60,7 +60,10 @@ int prc_stream_sync(void* stream);
 typedef enum prc_caf_method {
     PRC_CAF_AUTO = 0,
     PRC_CAF_DIRECT = 1,    /* time-domain lagged products in LDS tiles (any decimation FIR) */
-    PRC_CAF_FFT = 2        /* per-segment FFT correlation held in LDS/registers (boxcar FIR) */
+    PRC_CAF_FFT = 2,       /* per-segment FFT correlation held in LDS/registers (boxcar FIR):
+                              1024-point transforms, one wavefront per segment                 */
+    PRC_CAF_FFT4096 = 3    /* the same with 4096-point transforms by a team of four wavefronts:
+                              what AUTO takes for wide range spans (1025 lags and more)       */
 } prc_caf_method;
 
 typedef enum prc_doppler_method {
@@ -115,7 +118,9 @@ typedef struct prc_ls_desc {
     int32_t max_blocks;    /* workspace is sized for this many independent blocks           */
     int32_t method;        /* 0 auto (= 3 when it fits), 1 time-domain kernels, 2 FFT kernels that
                               recompute the reference spectra per Doppler bin, 3 FFT kernels with
-                              the reference spectra cached in HBM between Doppler bins       */
+                              the reference spectra cached in HBM between Doppler bins.  The FFT
+                              kernels take up to 769 taps on 1024-point transforms (one wavefront
+                              each) and up to 3073 taps on 4096-point transforms (four wavefronts) */
 } prc_ls_desc;
 
 typedef struct prc_ls_plan prc_ls_plan;

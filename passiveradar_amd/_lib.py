@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRCORE_LIB", os.path.join(_HERE, "libprcore.so"))   # override: A/B kernel builds
 
 PRC_OK, PRC_EINVAL, PRC_ESHAPE, PRC_EHIP, PRC_EROCFFT, PRC_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
-CAF_AUTO, CAF_DIRECT, CAF_FFT = 0, 1, 2
+CAF_AUTO, CAF_DIRECT, CAF_FFT, CAF_FFT4096 = 0, 1, 2, 3
 DOPPLER_AUTO, DOPPLER_ROCFFT = 0, 1
 COMM_ID_BYTES = 128
 

@@ -94,9 +94,22 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
     const bool boxcar = d->ntaps == 0;
     // resolve methods
     p->method = d->method;
-    if (p->method == PRC_CAF_AUTO)
+    if (p->method == PRC_CAF_AUTO) {
         p->method = caf_fft_supported(d->n, d->range_bins, d->freq_bins, boxcar) ? PRC_CAF_FFT
                                                                                  : PRC_CAF_DIRECT;
+        // wide range spans: a 4096-point team transform costs about 4.4 one-wavefront 1024-point transforms
+        // (four wavefronts, one more radix-16 pass); take it when the segment needs fewer of them
+        if (p->method == PRC_CAF_FFT && caf_team_supported(d->n, d->range_bins, d->freq_bins, boxcar) &&
+            4.4 * caf_team_blocking(p->ntaps, d->range_bins, nullptr, nullptr) <
+                caf_fft_blocking(p->ntaps, d->range_bins, nullptr, nullptr))
+            p->method = PRC_CAF_FFT4096;
+    }
+    if (p->method == PRC_CAF_FFT4096 && !caf_team_supported(d->n, d->range_bins, d->freq_bins, boxcar)) {
+        prc_set_error("prc_caf_plan_create: 4096-point FFT segment method unsupported for n=%lld R=%d F=%d%s",
+                      (long long)d->n, d->range_bins, d->freq_bins, boxcar ? "" : " (long FIR)");
+        delete p;
+        return PRC_EUNSUPPORTED;
+    }
     if (p->method == PRC_CAF_FFT && !caf_fft_supported(d->n, d->range_bins, d->freq_bins, boxcar)) {
         prc_set_error("prc_caf_plan_create: FFT segment method unsupported for n=%lld R=%d F=%d%s",
                       (long long)d->n, d->range_bins, d->freq_bins, boxcar ? "" : " (long FIR)");
@@ -117,7 +130,7 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
                       hipGetErrorString(hipGetLastError()));
         return fail(PRC_EHIP);
     }
-    if (p->method == PRC_CAF_FFT && p->doppler == PRC_DOPPLER_ROCFFT) {
+    if ((p->method == PRC_CAF_FFT || p->method == PRC_CAF_FFT4096) && p->doppler == PRC_DOPPLER_ROCFFT) {
         if (hipMalloc(&p->d_y2, p->y_bytes) != hipSuccess) {
             prc_set_error("prc_caf_plan_create: hipMalloc(%zu) failed", p->y_bytes);
             return fail(PRC_EHIP);
@@ -187,11 +200,11 @@ static int run_segments(prc_caf_plan* p, const void* ref, const void* srv, int64
     a.range_bins = p->desc.range_bins;
     a.freq_bins = p->desc.freq_bins;
     a.y_layout = PRC_Y_KJ;
-    if (p->method == PRC_CAF_FFT) {
-        // the FFT kernel writes whole rows y[j][0..R] (coalesced); rocFFT wants j contiguous
+    if (p->method == PRC_CAF_FFT || p->method == PRC_CAF_FFT4096) {
+        // the FFT kernels write whole rows y[j][0..R] (coalesced); rocFFT wants j contiguous
         a.y = p->d_y2;
         a.y_layout = PRC_Y_JK;
-        int rc = caf_launch_fft(a, nframes, stream);
+        int rc = p->method == PRC_CAF_FFT ? caf_launch_fft(a, nframes, stream) : caf_launch_fft_team(a, nframes, stream);
         if (rc) return rc;
         return caf_launch_transpose_jk_kj(p->d_y2, p->d_y, a.freq_bins, a.range_bins + 1, nframes, stream);
     }

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void transpose_jk_kj_kernel(const float2* __re
 
 // Lag blocking: nlb blocks of LB = ceil((R+1)/nlb) lags, pieces of B = 1025-LB samples.  One pass
 // over a segment costs pieces*(1+NLB) forward FFTs (+NLB inverse); pick the cheapest split.
-static void caf_fft_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out) {
+double caf_fft_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out) {
     double best = 1e300;
     int best_nlb = 1, best_lb = range_bins + 1;
     for (int nlb = 1; nlb <= 64; ++nlb) {
@@ -220,8 +220,9 @@ static void caf_fft_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_o
         if (cost < best) { best = cost; best_nlb = nlb; best_lb = lb; }
         if (lb <= 2) break;
     }
-    *nlb_out = best_nlb;
-    *lb_out = best_lb;
+    if (nlb_out) *nlb_out = best_nlb;
+    if (lb_out) *lb_out = best_lb;
+    return best;                                               // in 1024-point transforms per segment
 }
 
 bool caf_fft_supported(int64_t n, int range_bins, int freq_bins, int boxcar) {

@@ -1,0 +1,239 @@
+// Cross-ambiguity segment sums for wide range spans: 4096-point transforms by a four-wavefront team.
+//
+// Same algorithm as caf_fft.hip (range_doppler_processing.py:81-86 for the boxcar decimator, :72) --
+// per slow-time sample j the (q+1)-sample segment is cut into pieces, U = FFT(w ref piece), V = FFT(srv
+// piece extended by the lag span), Wacc += conj(U) V in registers, ONE inverse transform per segment and
+// lag block returns all its lags -- with the 4096-point team FFT of fft_team.h: a piece carries
+// 4097 - LB samples for LB lags, so 1025 lags (config 3: 1024 x 1024) cost 5 transforms of 4096 points
+// per 4883-sample segment instead of 32 of 1024, and 2049 lags (config 5) cost 5 instead of 58.
+// A last piece of only a few samples (config 5: 4097 = 2 x 2048 + 1) is not worth two transforms: its
+// lag products are added directly after the inverse transform (TAIL_MAX samples x 16 lags per thread).
+#include "caf_internal.h"
+#include "fft_team.h"
+#include <math.h>
+
+void ft_make_tables(float2* t) {
+    const double PI = 3.14159265358979323846;
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const double a = -2.0 * PI * (double)(k1 * n2) / 256.0;
+            t[k1 * 16 + n2] = make_float2((float)cos(a), (float)sin(a));
+        }
+    for (int m = 0; m < FT_P; ++m) {
+        const double a = -2.0 * PI * (double)m / (double)FT_P;
+        t[FT_TW1 + m] = make_float2((float)cos(a), (float)sin(a));
+    }
+}
+
+static float2* g_ft_tab[16] = {nullptr};
+static std::mutex g_ft_mtx;
+
+int ft_device_tables(const float2** out) {
+    int dev = 0;
+    PRC_HIP(hipGetDevice(&dev));
+    PRC_REQUIRE(dev >= 0 && dev < 16, PRC_EINVAL, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_ft_mtx);
+    if (!g_ft_tab[dev]) {
+        float2* host = new float2[FT_GTAB];
+        ft_make_tables(host);
+        float2* d = nullptr;
+        hipError_t e = hipMalloc(&d, sizeof(float2) * FT_GTAB);
+        if (e == hipSuccess) e = hipMemcpy(d, host, sizeof(float2) * FT_GTAB, hipMemcpyHostToDevice);
+        delete[] host;
+        PRC_HIP(e);
+        g_ft_tab[dev] = d;
+    }
+    *out = g_ft_tab[dev];
+    return PRC_OK;
+}
+
+#define CAFT_TAIL_MAX 16
+
+struct CafTeamArgs {
+    CafSegArgs s;
+    const float2* gtab;
+    int32_t piece;      // B = 4097 - lagblk samples of ref per transform
+    int32_t lagblk;     // lags per block (<= 3073)
+    int32_t nlagblk;    // lag blocks covering 0..range_bins
+    int32_t segs;       // consecutive slow-time samples per workgroup
+};
+
+template <bool HAS_WIN>
+__global__ __launch_bounds__(FT_THREADS, 2) void caf_fft_team_kernel(CafTeamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    const FtLane f = ft_setup(lds, a.gtab);
+    const int t = f.t;
+    const int b = blockIdx.y;
+    const float2* __restrict__ ref = a.s.ref + (int64_t)b * a.s.frame_stride;
+    const float2* __restrict__ srv = a.s.srv + (int64_t)b * a.s.frame_stride;
+    const float* __restrict__ win = a.s.window;
+    // frame-relative 32-bit arithmetic (n < 2^31); everything but t is workgroup-uniform
+    const int N = (int)a.s.n, NV = (int)a.s.n_valid;
+    const int R = a.s.range_bins;
+    const int B = a.piece, LB = a.lagblk;
+    const unsigned vo8 = (unsigned)t * 8u, vo4 = (unsigned)t * 4u;
+    auto clampu = [](int x) { return x < 0 ? 0u : (unsigned)x; };
+    const float sc = 1.0f / (float)FT_P;
+
+    for (int sg = 0; sg < a.segs; ++sg) {
+        const int64_t j = (int64_t)blockIdx.x * a.segs + sg;
+        if (j >= a.s.freq_bins) break;                         // uniform
+        const int64_t n_hi64 = j * a.s.q + a.s.half;
+        const int64_t n_lo64 = n_hi64 - (a.s.ntaps - 1);
+        const int lo = n_lo64 < 0 ? 0 : (int)n_lo64;
+        const int hi = n_hi64 > N - 1 ? N - 1 : (int)n_hi64;
+        // a short remainder after the last full piece goes the direct way
+        const int len = hi - lo + 1;
+        int tail = len % B;
+        if (tail > CAFT_TAIL_MAX || len < B) tail = 0;
+        const int hi_f = hi - tail;                            // last sample that goes through the transforms
+        float2* __restrict__ yrow = a.s.y + ((int64_t)b * a.s.freq_bins + j) * (R + 1);
+
+        for (int lb = 0; lb < a.nlagblk; ++lb) {
+            float2 acc[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) acc[m] = make_float2(0.f, 0.f);
+
+            // Software pipeline as in caf_fft.hip: raw buffer loads issued one transform ahead of their use; the
+            // descriptor's num_records encodes "samples of this piece that exist" (zero padding of U, ragged
+            // last piece, n_valid < n, the prefetch past the last piece).
+            float2 un[16];
+            float wn[16];
+            auto issue_u = [&](int n0) {
+                const int rem = hi_f - n0 + 1;
+                int cnt = rem < B ? rem : B;
+                if (NV - n0 < cnt) cnt = NV - n0;
+                const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + n0, clampu(cnt) * 8u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) un[r] = prc_buf_load_c64(ru, vo8, 2048u * r);
+                if (HAS_WIN) {
+                    const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + n0, clampu(cnt) * 4u);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) wn[r] = prc_buf_load_f32(rw, vo4, 1024u * r);
+                }
+            };
+            // srv slots [0, cnt+LB-1) of this lag block: frame offsets start .. with circular wrap (:82)
+            auto issue_v = [&](float2 (&v)[16], int n0, int cnt) {
+                int start = n0 + lb * LB;
+                if (start >= N) start -= N;
+                const int want = cnt + LB - 1;
+                int c1 = want;
+                if (N - start < c1) c1 = N - start;
+                if (NV - start < c1) c1 = NV - start;
+                const __amdgpu_buffer_rsrc_t rv = prc_rsrc(srv + start, clampu(c1) * 8u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = prc_buf_load_c64(rv, vo8, 2048u * r);
+                const int over = start + want - N;              // slots that wrapped (uniform, rare)
+                if (over > 0) {
+                    const __amdgpu_buffer_rsrc_t rw2 = prc_rsrc(srv, clampu(over < NV ? over : NV) * 8u);
+                    const unsigned voff = vo8 - (unsigned)(N - start) * 8u;   // threads before the wrap: out of range
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float2 w2 = prc_buf_load_c64(rw2, voff + 2048u * r, 0u);
+                        v[r].x += w2.x;
+                        v[r].y += w2.y;
+                    }
+                }
+            };
+            issue_u(lo);
+            for (int n0 = lo; n0 <= hi_f; n0 += B) {
+                const int rem = hi_f - n0 + 1;
+                const int cnt = rem < B ? rem : B;
+                float2 u[16], v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
+                issue_v(v, n0, cnt);
+                __builtin_amdgcn_sched_barrier(0);
+                ft4096_fwd<0>(u, f);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_u(n0 + B);                                // past the last piece: zero records -> zeros
+                __builtin_amdgcn_sched_barrier(0);
+                ft4096_fwd<1>(v, f);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) cmac_conj_a(acc[m], u[m], v[m]);
+            }
+            ft4096_inv<0>(acc, f);
+            ft_team_sync();                                     // the next pass starts at buffer 0 again
+            const int L0 = lb * LB;
+            if (tail > 0) {
+                // direct lag products of the last `tail` samples: acc is unnormalised (x 4096)
+                for (int i = 0; i < tail; ++i) {
+                    const int n1 = hi_f + 1 + i;
+                    float2 uu = make_float2(0.f, 0.f);
+                    if (n1 < NV) {
+                        uu = ref[n1];
+                        if (HAS_WIN) { const float w = win[n1]; uu.x *= w; uu.y *= w; }
+                    }
+                    uu.x *= (float)FT_P;
+                    uu.y *= (float)FT_P;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lag = L0 + 256 * r + t;
+                        int idx = n1 + lag;
+                        if (idx >= N) idx -= N;
+                        const bool ok = 256 * r + t < LB && lag <= R && idx < NV;
+                        const float2 sv = srv[ok ? idx : 0];
+                        if (ok) cmac_conj_a(acc[r], uu, sv);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int within = 256 * r + t;
+                const int lag = L0 + within;
+                if (within < LB && lag <= R) yrow[R - lag] = make_float2(acc[r].x * sc, -acc[r].y * sc);
+            }
+        }
+    }
+}
+
+// Lag blocking for 4096-point transforms: nlb blocks of LB = ceil((R+1)/nlb) lags, pieces of 4097-LB samples;
+// a pass over one lag block costs 2 transforms per piece + 1 inverse.  Returns the cost in 4096-point transforms.
+double caf_team_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out) {
+    double best = 1e300;
+    int best_nlb = 1, best_lb = range_bins + 1;
+    for (int nlb = 1; nlb <= 64; ++nlb) {
+        const int lb = (range_bins + nlb) / nlb;               // ceil((R+1)/nlb)
+        if (lb > 3073) continue;
+        const int64_t Bp = FT_P + 1 - lb;
+        int64_t pieces = q1 / Bp;
+        const int64_t rest = q1 % Bp;
+        if (rest > CAFT_TAIL_MAX || pieces == 0) ++pieces;
+        const double cost = (double)nlb * (2.0 * (double)pieces + 1.0);
+        if (cost < best) { best = cost; best_nlb = nlb; best_lb = lb; }
+        if (lb <= 2) break;
+    }
+    if (nlb_out) *nlb_out = best_nlb;
+    if (lb_out) *lb_out = best_lb;
+    return best;
+}
+
+bool caf_team_supported(int64_t n, int range_bins, int freq_bins, int boxcar) {
+    (void)freq_bins;
+    // n >= 8192 keeps a piece's 4096 slots from wrapping around the frame more than once
+    return boxcar && range_bins >= 1 && n >= 8192 && range_bins < n / 2;
+}
+
+int caf_launch_fft_team(const CafSegArgs& s, int nframes, hipStream_t stream) {
+    CafTeamArgs a;
+    a.s = s;
+    caf_team_blocking(s.ntaps, s.range_bins, &a.nlagblk, &a.lagblk);
+    a.piece = FT_P + 1 - a.lagblk;
+    int rc = ft_device_tables(&a.gtab);
+    if (rc) return rc;
+    // several segments per workgroup amortise the table set-up once there is plenty of work
+    const int64_t total = (int64_t)s.freq_bins * nframes;
+    a.segs = total >= 16384 ? 4 : (total >= 4096 ? 2 : 1);
+    dim3 grid((unsigned)((s.freq_bins + a.segs - 1) / a.segs), (unsigned)nframes);
+    const size_t lds = sizeof(float2) * FT_LDS_ELEMS;
+    PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s.window ? &caf_fft_team_kernel<true> : &caf_fft_team_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (s.window)
+        hipLaunchKernelGGL((caf_fft_team_kernel<true>), grid, dim3(FT_THREADS), lds, stream, a);
+    else
+        hipLaunchKernelGGL((caf_fft_team_kernel<false>), grid, dim3(FT_THREADS), lds, stream, a);
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}

@@ -36,5 +36,11 @@ __device__ __forceinline__ void caf_store_y(const CafSegArgs& a, int frame, int6
 int caf_launch_direct(const CafSegArgs& a, int nframes, hipStream_t stream);
 int caf_launch_fft(const CafSegArgs& a, int nframes, hipStream_t stream);
 bool caf_fft_supported(int64_t n, int range_bins, int freq_bins, int ntaps_is_boxcar);
+// 4096-point team transforms (caf_fft_team.hip); the *_blocking functions return the cost of one segment in
+// transforms of their own size
+int caf_launch_fft_team(const CafSegArgs& a, int nframes, hipStream_t stream);
+bool caf_team_supported(int64_t n, int range_bins, int freq_bins, int ntaps_is_boxcar);
+double caf_team_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out);
+double caf_fft_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out);
 int caf_launch_transpose_jk_kj(const float2* src, float2* dst, int freq_bins, int cols, int nframes,
                                hipStream_t stream);

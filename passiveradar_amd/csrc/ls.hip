@@ -571,7 +571,8 @@ struct prc_ls_plan {
     int T;
     int nblk;          // partial-sum slots per block (tiles of the direct kernel / waves of the FFT kernel)
     int method;        // 1 time-domain, 2 FFT
-    int fft_waves;     // waves per block in the FFT correlation kernel
+    int fft_waves;     // waves (1024-point kernels) or teams (4096-point kernels) per block in the FFT correlation kernel
+    bool team = false; // 770 .. 3073 taps: the 4096-point team kernels of ls_fft_team.hip
     float2* d_partial = nullptr;
     double2* d_taps = nullptr;
     float2* d_tmp[2] = {nullptr, nullptr};
@@ -622,20 +623,23 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     p->desc = *d;
     p->T = T;
     p->method = d->method;
-    if (p->method == 0) p->method = ls_fft_supported(T) ? 2 : 1;
+    if (p->method == 0) p->method = (ls_fft_supported(T) || ls_team_supported(T)) ? 2 : 1;
     if (p->method == 3) p->method = 2;          // same kernels; d->method == 3 only adds the spectrum cache
     if (p->method == 2 && !ls_fft_supported(T)) {
-        prc_set_error("prc_ls_plan_create: FFT method supports at most 769 taps, got %d", T);
-        delete p;
-        return PRC_EUNSUPPORTED;
+        if (!ls_team_supported(T)) {
+            prc_set_error("prc_ls_plan_create: FFT method supports at most 3073 taps, got %d", T);
+            delete p;
+            return PRC_EUNSUPPORTED;
+        }
+        p->team = true;                         // beyond the 1024-point transform: 4096-point team kernels
     }
-    p->fft_waves = ls_fft_waves_per_block(d->n, T);
+    p->fft_waves = p->team ? ls_team_teams_per_block(d->n, T) : ls_fft_waves_per_block(d->n, T);
     p->nblk = p->method == 2 ? p->fft_waves : (int)ceil_div64(d->n, LSC_BLK);
     hipError_t e = hipMalloc(&p->d_partial, sizeof(float2) * (size_t)d->max_blocks * p->nblk * 2 * T);
     if (e == hipSuccess) e = hipMalloc(&p->d_taps, sizeof(double2) * (size_t)d->max_blocks * T);
     if (e == hipSuccess) e = hipMalloc(&p->d_tmp[0], sizeof(float2) * (size_t)d->max_blocks * d->n);
     if (e == hipSuccess) e = hipMalloc(&p->d_tmp[1], sizeof(float2) * (size_t)d->max_blocks * d->n);
-    if (e == hipSuccess && p->method == 2 && !d->circular) {
+    if (e == hipSuccess && p->method == 2 && !d->circular && !p->team) {
         e = hipMalloc(&p->d_c0, sizeof(double2) * (size_t)d->max_blocks * T);
         if (e == hipSuccess) e = hipMalloc(&p->d_se, sizeof(double2) * (size_t)d->max_blocks * T);
         if (e == hipSuccess) e = hipMalloc(&p->d_tinv, sizeof(double2) * (size_t)d->max_blocks * T * T);
@@ -842,7 +846,8 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
             if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 0], stream));
             int rc;
             if (p->method == 2) {
-                rc = ls_launch_corr_fft(xa, theta, p->fft_waves, nblocks, true, stream);
+                rc = p->team ? ls_launch_corr_team(xa, theta, p->fft_waves, nblocks, true, stream)
+                             : ls_launch_corr_fft(xa, theta, p->fft_waves, nblocks, true, stream);
             } else {
                 CorrArgs ca;
                 ca.p_src = (const float2*)ref;  ca.p_stride = stride;
@@ -865,7 +870,7 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
             PRC_LAUNCH_CHECK();
             if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
             if (p->method == 2) {
-                rc = ls_launch_fir_fft(xa, theta, nblocks, stream);
+                rc = p->team ? ls_launch_fir_team(xa, theta, nblocks, stream) : ls_launch_fir_fft(xa, theta, nblocks, stream);
                 if (rc) return rc;
             } else {
                 FirArgs fa;

@@ -40,3 +40,9 @@ int64_t ls_cache_elems_per_block(int64_t n, int T);
 int ls_launch_corr_cached(LsFftArgs a, double theta, int waves_per_block, int nblocks, hipStream_t stream);
 int ls_launch_fused_cached(LsFftArgs a, double theta, double theta_out, double gamma_angle, int waves_per_block,
                            int nblocks, hipStream_t stream);
+// 4096-point team kernels (ls_fft_team.hip): 770 .. 3073 taps, per-bin correlate -> Levinson -> FIR
+bool ls_team_supported(int T);
+int ls_team_teams_per_block(int64_t n, int T);
+int ls_launch_corr_team(LsFftArgs a, double theta, int teams_per_block, int nblocks, bool with_autocorr,
+                        hipStream_t stream);
+int ls_launch_fir_team(LsFftArgs a, double theta, int nblocks, hipStream_t stream);

@@ -21,7 +21,7 @@ _DEFAULTS = {"caf": _lib.CAF_AUTO, "doppler": _lib.DOPPLER_AUTO}
 
 
 def set_default_methods(caf=None, doppler=None):
-    """caf: 0 auto | 1 direct | 2 fft;  doppler: 0 auto | 1 rocfft."""
+    """caf: 0 auto | 1 direct | 2 fft (1024-point) | 3 fft (4096-point team);  doppler: 0 auto | 1 rocfft."""
     if caf is not None:
         _DEFAULTS["caf"] = int(caf)
     if doppler is not None:
@@ -45,7 +45,7 @@ def _long_taps(q):
 def caf_plan_for(n, rangeBins, freqBins, shortFilt=True, max_frames=1, method=None, doppler=None, stream=None):
     method = _DEFAULTS["caf"] if method is None else method
     doppler = _DEFAULTS["doppler"] if doppler is None else doppler
-    if not shortFilt and method == _lib.CAF_FFT:
+    if not shortFilt and method in (_lib.CAF_FFT, _lib.CAF_FFT4096):
         method = _lib.CAF_AUTO          # the long FIR only exists in the time-domain kernel
     q = int(n / freqBins) if freqBins else 0
     key = ("caf", n, rangeBins, freqBins, bool(shortFilt), max_frames, method, doppler)

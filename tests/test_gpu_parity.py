@@ -474,3 +474,144 @@ def test_ls_cfg1_chunk_golden():
     scale = np.abs(g["head"]).max()
     assert np.abs(out[::7] - g["out_sub"]).max() / scale < 1e-5
     assert np.abs(out[:600] - g["head"]).max() / scale < 1e-5 and np.abs(out[-600:] - g["tail"]).max() / scale < 1e-5
+
+
+@pytest.mark.parametrize("name", ["ls_multiple_bin50", "ls_multiple_kHz"])
+def test_ls_multiple_far_doppler_bins(name, ls_method):
+    """Doppler bins far from zero (the reference takes any list, clutter_removal.py:178-187): 50 Hz at 10 kHz and
+    +-1.5 kHz at 262 kHz put |2 pi f/Fs| * peek at 0.3-0.4 rad, beyond the Taylor range of the wrapped-sample phase --
+    every kernel family must take them (round 1 refused them in auto mode)."""
+    from passiveradar_amd.clutter_removal import LS_Filter_Multiple
+    g = load_golden(name)
+    out = LS_Filter_Multiple(g["ref"], g["srv"], int(g["L"]), float(g["fs"]), [float(b) for b in g["bins"]])
+    assert rel_err(out, g["out"]) < TOL
+
+
+def test_ls_far_bins_long_block_chain():
+    """the cached-spectrum chain (long blocks) with bins of hundreds of Hz, against the float64 oracle"""
+    from passiveradar_amd import clutter_removal as cr
+    n, L, fs = 200000, 40, 262184.87
+    ref, srv = scene.make_scene(n, fs, L, 2718)
+    bins = [0.0, 300.0, -450.0, 2.0]
+    exp = O.LS_Filter_Multiple(ref, srv, L, fs, bins)
+    for m in (0, 1, 2, 3):
+        cr.set_default_ls_method(m)
+        try:
+            out = cr.LS_Filter_Multiple(ref, srv, L, fs, bins)
+        finally:
+            cr.set_default_ls_method(0)
+        assert rel_err(out, exp) < TOL, m
+
+
+def test_ls_at_the_config3_tap_count(ls_method):
+    """T = 1034 (config 3's filter length, > the 769 taps of the 1024-point kernels) against the reference's own
+    outputs: Toeplitz (+ taps), the three-bin chain, and the circular direct form"""
+    from passiveradar_amd.clutter_removal import LS_Filter, LS_Filter_Multiple, LS_Filter_Toeplitz
+    g = load_golden("ls_t1034")
+    n, L, fs = int(g["N"]), int(g["L"]), float(g["fs"])
+    a, s = scene.make_scene(n, fs, L, int(g["seed"]))
+    out, taps = LS_Filter_Toeplitz(a, s, L, return_filter=True)
+    assert rel_err(taps, g["taps"]) < TIGHT and rel_err(out, g["out"]) < TIGHT
+    assert rel_err(LS_Filter_Multiple(a, s, L, fs, [float(b) for b in g["bins"]]), g["out_multiple"]) < TOL
+    g = load_golden("ls_direct_t1034")
+    a, s = scene.make_scene(int(g["N"]), float(g["fs"]), L, int(g["seed"]))
+    out, taps = LS_Filter(a, s, L, return_filter=True)
+    assert rel_err(taps, g["taps"]) < 5e-5 and rel_err(out, g["out"]) < 1e-3     # reference: complex64 solve and apply
+
+
+def test_ls_t1034_long_block_vs_oracle(ls_method):
+    """config-3-shaped LS_Filter_Multiple (T = 1034) on a block long enough for the cached chain"""
+    from passiveradar_amd.clutter_removal import LS_Filter_Multiple
+    n, L, fs = 300000, 1024, 1.0e7
+    ref, srv = scene.make_scene(n, fs, L, 1034)
+    exp = O.LS_Filter_Multiple(ref, srv, L, fs, [0, 1, -1, 2, -2])
+    out = LS_Filter_Multiple(ref, srv, L, fs, [0, 1, -1, 2, -2])
+    assert rel_err(out, exp) < TOL
+
+
+def test_nlms_full_cfg3_hop_vs_c_oracle():
+    """config 3's NLMS stage at FULL hop length: 2.5 M samples, T = 1034, mu = 0.02, one stream, against the C twin
+    of the oracle (2.4 M sequential steps: drift between two float32 summation orders would show here)"""
+    import time
+    from oracle import c_oracle
+    from passiveradar_amd.clutter_removal import NLMS_filter
+    n, L = 2500000, 1024
+    ref, srv = scene.make_scene(n, 1.0e7, L, scene.scene_seed(3))
+    t0 = time.time()
+    exp, etaps = c_oracle.nlms(ref, srv, L, 0.02, 10)
+    t1 = time.time()
+    out, taps = NLMS_filter(ref, srv, L, 0.02, 10, None, True)
+    print(f"C twin {t1 - t0:.1f}s, device {time.time() - t1:.1f}s")
+    assert rel_err(out, exp) < TOL and rel_err(taps, etaps) < TOL
+    assert rel_err(out[-50000:], exp[-50000:]) < TOL          # no drift at the far end either
+
+
+def test_nlms_reference_level_step():
+    """the reference channel drops by 50 dB (and comes back) inside the tap window: u^H u must follow exactly,
+    as the reference's per-step re-sum does (:213) -- a float32 sliding sum alone loses it to cancellation"""
+    from oracle import c_oracle
+    from passiveradar_amd.clutter_removal import NLMS_filter
+    for L, n in ((24, 6000), (200, 9000)):
+        ref, srv = scene.make_scene(n, 1e5, L, 5050 + L)
+        g = np.ones(n, np.float32)
+        g[n // 3:n // 2] = 10 ** (-50 / 20)
+        ref2 = (ref * g).astype(np.complex64)
+        srv2 = (srv * g + 0.001 * srv).astype(np.complex64)
+        exp, etaps = c_oracle.nlms(ref2, srv2, L, 0.05, 10)
+        out, taps = NLMS_filter(ref2, srv2, L, 0.05, 10, None, True)
+        assert np.isfinite(out).all()
+        assert rel_err(out, exp) < TOL and rel_err(taps, etaps) < TOL, L
+
+
+# ---- 4096-point team transforms (caf_fft_team.hip): forced through the plan, every branch of the kernel ----
+@pytest.fixture
+def caf_team():
+    from passiveradar_amd import range_doppler_processing as rdp
+    rdp.set_default_methods(caf=3)
+    yield
+    rdp.set_default_methods(caf=0)
+
+
+@pytest.mark.parametrize("n,R,F,win,n_in", [
+    (8192, 70, 2, True, None),        # one piece per segment, 71 lags
+    (65536, 300, 16, True, None),     # q+1 = 4097 -> one piece of 3796 + remainder piece
+    (65536, 1024, 8, True, None),     # config-3 lag span: pieces of 3072
+    (131072, 2048, 32, True, None),   # config-5 segment shape: 4097 = 2 x 2048 + 1 -> the direct tail sample
+    (1 << 17, 2040, 32, False, None), # tail of 9 samples (B = 2056), no window
+    (100000, 3500, 4, True, None),    # two lag blocks of 1751, pieces of 2346, odd q
+    (40000, 9000, 2, False, None),    # five lag blocks, wrap of srv inside pieces
+    (20000, 700, 3, True, 17000),     # zero-pad branch: n_valid < n
+    (8192, 4000, 1, False, None),     # range span close to n/2, everything wraps
+])
+def test_caf_team_vs_oracle_shapes(n, R, F, win, n_in, caf_team):
+    from passiveradar_amd.range_doppler_processing import fast_xambg
+    m = n if n_in is None else n_in
+    ref, srv = scene.make_scene(m, 1e4, min(R, 200), 9090 + n + R)
+    w = np.kaiser(n, 5.0) if win else None
+    exp = O.fast_xambg(ref, srv, R, F, n, w)
+    out = fast_xambg(ref, srv, R, F, n, w)
+    assert out.shape == (F, R + 1, 1)
+    e = rel_err(out, exp)
+    assert e < TIGHT, e
+
+
+@pytest.mark.parametrize("name", ["caf_cfg1", "caf_cfg2"])
+def test_caf_team_full_size_golden(name, caf_team):
+    """the reference's own full-size config-1 / config-2 surfaces through the 4096-point kernel (AUTO keeps the
+    1024-point one for these 257-lag spans; forced here)"""
+    from scipy.signal import get_window
+    from passiveradar_amd.range_doppler_processing import fast_xambg
+    g = load_golden(name)
+    n, R, F = int(g["N"]), int(g["R"]), int(g["F"])
+    ref, srv = scene.make_scene(n, float(g["fs"]), R, int(g["seed"]))
+    out = fast_xambg(ref, srv, R, F, n, get_window(("kaiser", 5.0), n))
+    assert rel_err(out, g["out"]) < TOL
+
+
+def test_caf_auto_picks_the_team_kernel_for_wide_spans():
+    from passiveradar_amd import _lib
+    from passiveradar_amd.range_doppler_processing import caf_plan_for
+    assert caf_plan_for(2400000, 256, 512).method == _lib.CAF_FFT              # config 2
+    assert caf_plan_for(5000000, 1024, 1024).method == _lib.CAF_FFT4096       # config 3
+    assert caf_plan_for(1 << 23, 2048, 2048).method == _lib.CAF_FFT4096       # config 5
+    assert caf_plan_for(4096, 7, 64).method == _lib.CAF_FFT

@@ -165,6 +165,26 @@ def test_cfg2_pipeline_against_reference_output():
     assert rel_err(X, Xo) < 1e-5
 
 
+def test_cfg2_pipeline_against_complex128_reference_output():
+    """BASELINE config 2 end to end at full size against the map the reference produces when its own functions are
+    fed complex128 inputs (tests/golden/pipeline_cfg2_c128.npz: scipy.signal.correlate then sums the 1.2 M-term
+    correlations in double, clutter_removal.py:142-155).  This is the north-star statement without caveat:
+    max|X - X_ref| / max|X_ref| < 1e-4 on EVERY cell, zero-Doppler ridge included; measured ~1e-6."""
+    from passiveradar_amd import scene
+    from passiveradar_amd.stream import HipBackend, StreamProcessor
+    g = load_golden("pipeline_cfg2_c128")
+    n, R, F, fs = int(g["N"]), int(g["R"]), int(g["F"]), float(g["fs"])
+    C = n // 2
+    a, s = scene.make_stream(3, C, fs, R, int(g["seed"]))
+    be = HipBackend(n, R, F, fs, batch=3)
+    X = StreamProcessor(be).process(a, s)[int(g["frame_index"])].cpu().numpy()
+    e = rel_err(X, g["out"])
+    print("cfg2 pipeline vs complex128-input reference:", e)
+    assert e < 1e-4
+    clean = be.clean(be.padded(a), be.padded(s), 3)[C // 2:C // 2 + 3 * C].cpu().numpy()
+    assert rel_err(clean[::101], g["cleaned_sub"]) < 1e-5
+
+
 def test_stream_with_nlms_canceller():
     """HipBackend(clutter='nlms'): every hop chunk is an independent NLMS stream (batched launch), frames from the
     cleaned stream -- against per-chunk NLMS (C twin of the oracle) + the oracle's CAF on the overlapped frames"""
