@@ -8,6 +8,20 @@
 // per 4883-sample segment instead of 32 of 1024, and 2049 lags (config 5) cost 5 instead of 58.
 // A last piece of only a few samples (config 5: 4097 = 2 x 2048 + 1) is not worth two transforms: its
 // lag products are added directly after the inverse transform (TAIL_MAX samples x 16 lags per thread).
+//
+// Occupancy (measured on MI355X, config 3 / config 5 segment kernels, A/B on one box): the first form of this
+// kernel -- two exchange buffers (one barrier per forward transform), inputs prefetched one transform ahead,
+// 236 VGPRs = 2 wavefronts per SIMD -- ran at 35.6 ms per 1024 config-3 frames; one exchange buffer (two barriers
+// per transform, 37 KB of LDS per workgroup), no prefetch and <= 168 VGPRs = 3 wavefronts per SIMD runs at 30.7 ms
+// (-14 %; config 5: 2.93 -> 2.49 ms per 32 surfaces).  Forcing 4 wavefronts per SIMD spills and is slower (40 ms);
+// removing every barrier (wrong results, upper bound) would give 31.0 ms at 2 wavefronts per SIMD.
+#ifndef FT_NBUF
+#define FT_NBUF 1
+#endif
+#ifndef CAFT_WAVES_PER_SIMD
+#define CAFT_WAVES_PER_SIMD 3
+#define CAFT_NO_PREFETCH 1
+#endif
 #include "caf_internal.h"
 #include "fft_team.h"
 #include <math.h>
@@ -58,8 +72,11 @@ struct CafTeamArgs {
     int32_t segs;       // consecutive slow-time samples per workgroup
 };
 
+#ifndef CAFT_WAVES_PER_SIMD
+#define CAFT_WAVES_PER_SIMD 2
+#endif
 template <bool HAS_WIN>
-__global__ __launch_bounds__(FT_THREADS, 2) void caf_fft_team_kernel(CafTeamArgs a) {
+__global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_kernel(CafTeamArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
     const FtLane f = ft_setup(lds, a.gtab);
@@ -136,6 +153,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void caf_fft_team_kernel(CafTeamArgs
                     }
                 }
             };
+#ifndef CAFT_NO_PREFETCH
             issue_u(lo);
             for (int n0 = lo; n0 <= hi_f; n0 += B) {
                 const int rem = hi_f - n0 + 1;
@@ -151,6 +169,23 @@ __global__ __launch_bounds__(FT_THREADS, 2) void caf_fft_team_kernel(CafTeamArgs
                 issue_u(n0 + B);                                // past the last piece: zero records -> zeros
                 __builtin_amdgcn_sched_barrier(0);
                 ft4096_fwd<1>(v, f);
+#else
+            // high-occupancy form: nothing is loaded ahead (the other wavefronts of the SIMD cover the latency)
+            // and only u, v and the accumulator are ever live together
+            for (int n0 = lo; n0 <= hi_f; n0 += B) {
+                const int rem = hi_f - n0 + 1;
+                const int cnt = rem < B ? rem : B;
+                float2 u[16], v[16];
+                issue_u(n0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
+                __builtin_amdgcn_sched_barrier(0);
+                ft4096_fwd<0>(u, f);
+                __builtin_amdgcn_sched_barrier(0);
+                issue_v(v, n0, cnt);
+                ft4096_fwd<1>(v, f);
+#endif
 #pragma unroll
                 for (int m = 0; m < 16; ++m) cmac_conj_a(acc[m], u[m], v[m]);
             }

@@ -37,7 +37,10 @@
 #define FT_PITCH 17                     // float2 per thread row of an exchange buffer
 #define FT_BUF (FT_THREADS * FT_PITCH)  // float2 per exchange buffer
 #define FT_TW1 256                      // W_256^(n2 k1), [k1][n2]
-#define FT_LDS_ELEMS (FT_TW1 + 2 * FT_BUF)                   // float2 elements of LDS per workgroup (71 680 B)
+#ifndef FT_NBUF
+#define FT_NBUF 2                       // exchange buffers: 2 = one barrier per forward transform; 1 = two barriers, half the LDS
+#endif
+#define FT_LDS_ELEMS (FT_TW1 + FT_NBUF * FT_BUF)             // float2 elements of LDS per workgroup (71 680 B with two buffers)
 #define FT_GTAB (FT_TW1 + FT_P)         // global table: TW1 then W_4096^m, m = 0..4095
 
 struct FtLane {
@@ -46,8 +49,22 @@ struct FtLane {
     float2* wr;         // exchange base + 17 t           : write (t, rho) at wr[rho]            (+ FT_BUF for buffer 1)
     const float2* rdA;  // exchange base + 272 hi + lo    : row-private read (16 hi + m, lo) at rdA[17 m]
     const float2* rdB;  // exchange base + 17 lo + hi     : cross-wave read (16 m + lo, hi) at rdB[272 m]
+#ifdef FT_TW2_FACTORED
+    float2 tw2b;        // W_4096^(lo hi); the k2 part W_256^(lo k2) comes from the TW1 table (tw2t[16 k2])
+    const float2* tw2t; // lds + lo
+#else
     float2 tw2[16];     // W_4096^(lo (hi + 16 k2))
+#endif
 };
+
+// T2 twiddle of register k2 (forward sense; the inverse multiplies by its conjugate)
+__device__ __forceinline__ float2 ft_tw2(const FtLane& f, int k2) {
+#ifdef FT_TW2_FACTORED
+    return k2 == 0 ? f.tw2b : cmul(f.tw2b, f.tw2t[16 * k2]);
+#else
+    return f.tw2[k2];
+#endif
+}
 
 // Fill the TW1 table in LDS and this thread's T2 constants from the host-made global table; ends with
 // __syncthreads().  lds: FT_LDS_ELEMS float2.
@@ -61,43 +78,54 @@ __device__ __forceinline__ FtLane ft_setup(float2* lds, const float2* __restrict
     f.rdA = x + 16 * FT_PITCH * hi + lo;
     f.rdB = x + FT_PITCH * lo + hi;
     lds[f.t] = gtab[f.t];               // FT_TW1 == FT_THREADS
+#ifdef FT_TW2_FACTORED
+    f.tw2b = gtab[FT_TW1 + lo * hi];
+    f.tw2t = lds + lo;
+#else
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) f.tw2[k2] = gtab[FT_TW1 + ((lo * (hi + 16 * k2)) & (FT_P - 1))];
+#endif
     __syncthreads();
     return f;
 }
 
-__device__ __forceinline__ void ft_team_sync() { __syncthreads(); }
+#ifndef FT_BARRIER
+#define FT_BARRIER() __syncthreads()
+#endif
+__device__ __forceinline__ void ft_team_sync() { FT_BARRIER(); }
 
 // Forward FFT: time layout -> frequency layout.  CUR: buffer of the cross-wave exchange (alternate 0, 1, 0, ...).
 template <int CUR>
 __device__ __forceinline__ void ft4096_fwd(float2 (&x)[16], const FtLane& f) {
-    constexpr int T = CUR * FT_BUF, O = (CUR ^ 1) * FT_BUF;
+    constexpr int T = (FT_NBUF == 2 ? CUR : 0) * FT_BUF, O = (FT_NBUF == 2 ? (CUR ^ 1) : 0) * FT_BUF;
     dft16<1>(x);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) x[k1] = mul_tw<1>(x[k1], f.tw1[16 * k1]);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) f.wr[T + k1] = x[k1];
-    __syncthreads();
+    FT_BARRIER();
 #pragma unroll
     for (int m = 0; m < 16; ++m) x[m] = f.rdB[T + 16 * FT_PITCH * m];
+    if (FT_NBUF == 1) FT_BARRIER();       // single buffer: every cross-wave read phase is closed by a barrier
     dft16<1>(x);
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) x[k2] = mul_tw<1>(x[k2], f.tw2[k2]);
+    for (int k2 = 0; k2 < 16; ++k2) x[k2] = mul_tw<1>(x[k2], ft_tw2(f, k2));
+#ifndef FT_EXP_NOX2
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) f.wr[O + k2] = x[k2];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 16; ++j) x[j] = f.rdA[O + FT_PITCH * j];
     __builtin_amdgcn_wave_barrier();
+#endif
     dft16<1>(x);
 }
 
 // Inverse FFT (unnormalised): frequency layout -> time layout.  Both exchanges in buffer CUR.
 template <int CUR>
 __device__ __forceinline__ void ft4096_inv(float2 (&x)[16], const FtLane& f) {
-    constexpr int T = CUR * FT_BUF;
-    __syncthreads();                      // the buffer must be quiet before the row-private exchange below
+    constexpr int T = (FT_NBUF == 2 ? CUR : 0) * FT_BUF;
+    if (FT_NBUF == 2) FT_BARRIER();       // the buffer must be quiet before the row-private exchange below
     dft16<-1>(x);
 #pragma unroll
     for (int j = 0; j < 16; ++j) f.wr[T + j] = x[j];
@@ -106,13 +134,14 @@ __device__ __forceinline__ void ft4096_inv(float2 (&x)[16], const FtLane& f) {
     for (int m = 0; m < 16; ++m) x[m] = f.rdA[T + FT_PITCH * m];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) x[k2] = mul_tw<-1>(x[k2], f.tw2[k2]);
+    for (int k2 = 0; k2 < 16; ++k2) x[k2] = mul_tw<-1>(x[k2], ft_tw2(f, k2));
     dft16<-1>(x);
 #pragma unroll
     for (int m = 0; m < 16; ++m) f.wr[T + m] = x[m];
-    __syncthreads();
+    FT_BARRIER();
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) x[k1] = f.rdB[T + 16 * FT_PITCH * k1];
+    if (FT_NBUF == 1) FT_BARRIER();
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) x[k1] = mul_tw<-1>(x[k1], f.tw1[16 * k1]);
     dft16<-1>(x);

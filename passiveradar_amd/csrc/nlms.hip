@@ -15,8 +15,6 @@
 // workgroup barrier anywhere.
 #include "common.h"
 
-#define NLMS_RESUM 64      // steps between exact re-sums of u^H u (see the step loop)
-
 struct NlmsArgs {
     const float2* ref;
     const float2* srv;
@@ -114,23 +112,26 @@ __global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
         }
         for (int x = lane; x < cnt; x += 64) D[x] = srv[k0 + x + a.L];
         wave_lds_fence();
-        // u^H u is summed exactly every NLMS_RESUM steps and slid in between:
+        // u^H u is summed at the start of every staged window and then slid IN DOUBLE PRECISION:
         //   E(k+1) = E(k) + |ref[T+k+1]|^2 - |ref[k+1]|^2      (window element kk+WIN enters, kk+WIN-T leaves)
-        // The reference re-sums at every step (:213), so its value never carries cancellation error; a float32
-        // slide does when the reference level falls sharply inside the window.  Besides the periodic re-sum, the
-        // slide is therefore replaced by an exact sum as soon as the energy has dropped 16x below the last exact
-        // value (wave-uniform, rarely taken branch): the relative error of `en` stays below ~1e-4 whatever the input.
-        auto exact_energy = [&](int kk) {
-            float e0 = 0.f;
+        // The reference re-sums at every step (:213), so its value never carries cancellation error.  A float32
+        // slide does when the reference level falls sharply inside the tap window (a 50 dB drop leaves an energy
+        // that is mostly rounding error, mu / en then blows up); the squares of float32 samples are exact in
+        // double and the running sum is good to 1e-16 of the largest energy seen, so the slid value equals the
+        // reference's per-step sum to float32 accuracy whatever the input does (four f64 FMAs per step).
+        double energy;
+        {   // the window's first sum in double as well (a float32 sum would leave a 1e-7 E bias for the whole window)
+            double e0 = 0.0;
 #pragma unroll
             for (int t = 0; t < TPL; ++t) {
                 const int i = lane + 64 * t;
-                const float2 v = Rw[kk + WIN - 1 - i];
-                if (i < T) e0 = fmaf(v.x, v.x, fmaf(v.y, v.y, e0));
+                const float2 v = Rw[WIN - 1 - i];
+                if (i < T) e0 = fma((double)v.x, (double)v.x, fma((double)v.y, (double)v.y, e0));
             }
-            return wave_allsum(e0);
-        };
-        float energy = 0.f, elow = 0.f;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) e0 += __shfl_xor(e0, m, 64);
+            energy = e0;
+        }
         // One step: dot (registers), two DPP reductions, AXPY.  The sliding window of the NEXT step
         // is fetched from LDS while this step reduces (ua/ub swap roles, loop unrolled by two), so
         // the only latency left on the critical path is the reduction itself.
@@ -154,14 +155,14 @@ __global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
             fetch(unext, kk + 1);                    // independent of this step's result
             yr = wave_allsum(yr);
             yi = wave_allsum(yi);
-            const float en = energy;
+            const float en = (float)energy;
             {   // slide the energy to the next step (wave-uniform LDS reads, broadcast)
                 const float2 vin = Rw[kk + WIN], vout = Rw[kk + WIN - T];
-                energy += (vin.x * vin.x + vin.y * vin.y) - (vout.x * vout.x + vout.y * vout.y);
-                if (energy < elow) {                 // fell 16x since the last exact sum: cancellation -> re-sum
-                    energy = exact_energy(kk + 1);
-                    elow = energy * 0.0625f;
-                }
+                const double ix = (double)vin.x, iy = (double)vin.y, ox = (double)vout.x, oy = (double)vout.y;
+                energy = fma(ix, ix, energy);
+                energy = fma(iy, iy, energy);
+                energy = fma(-ox, ox, energy);
+                energy = fma(-oy, oy, energy);
             }
             const float2 d = D[kk];
             const float er = d.x - yr, ei = d.y - yi;
@@ -172,18 +173,13 @@ __global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
             if (lane == 0) D[kk] = make_float2(er, ei);
         };
         v2f ua[TPL], ub[TPL];
-        for (int kb = 0; kb < cnt; kb += NLMS_RESUM) {
-            const int ke = kb + NLMS_RESUM < cnt ? kb + NLMS_RESUM : cnt;
-            energy = exact_energy(kb);
-            elow = energy * 0.0625f;
-            fetch(ua, kb);
-            int kk = kb;
-            for (; kk + 2 <= ke; kk += 2) {
-                step(ua, ub, kk);
-                step(ub, ua, kk + 1);
-            }
-            if (kk < ke) step(ua, ub, kk);
+        fetch(ua, 0);
+        int kk = 0;
+        for (; kk + 2 <= cnt; kk += 2) {
+            step(ua, ub, kk);
+            step(ub, ua, kk + 1);
         }
+        if (kk < cnt) step(ua, ub, kk);
         wave_lds_fence();
         for (int x = lane; x < cnt; x += 64) out[a.L + k0 + x] = D[x];
     }

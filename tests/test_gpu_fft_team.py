@@ -8,11 +8,12 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "csrc", "libfftprobe.so")
 
 
-@pytest.fixture(scope="module")
-def probe(gpu_ready):
+@pytest.fixture(scope="module", params=["libfftprobe.so", "libfftprobe1.so"],
+                ids=["two_buffers_one_barrier", "one_buffer_two_barriers"])
+def probe(request, gpu_ready):
+    LIB = os.path.join(HERE, "csrc", request.param)
     if not os.path.exists(LIB):
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(HERE, "csrc")])
