@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--caf-method", type=int, default=0, help="0 auto, 1 direct, 2 fft")
     ap.add_argument("--ls-method", type=int, default=0, help="0 auto, 1 time-domain, 2 FFT, 3 FFT + spectrum cache")
     ap.add_argument("--nsub", type=int, default=2, help="LS sub-batches per CAF sub-batch when stages are pipelined")
+    ap.add_argument("--ls-streams", type=int, default=2, help="LS chains in flight (alternate sub-batches on separate streams)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run LS and CAF back to back on one stream instead of pipelining sub-batches on two")
     ap.add_argument("--gather", default="auto", choices=["auto", "prc", "torch", "none"],
@@ -225,7 +226,7 @@ def main():
     batch = min(sub, max(nframes, 1))
     be = prstream.HipBackend(n, R, F, fs, clutter=clutter, batch=batch, device=device,
                              caf_method=args.caf_method, overlap=not args.no_overlap,
-                             ls_method=args.ls_method, nsub=args.nsub)
+                             ls_method=args.ls_method, nsub=args.nsub, ls_streams=args.ls_streams)
 
     # ---- synthetic IQ resident in HBM --------------------------------------------------------------
     seed0 = 20260926 + (rank if not strong else 0)

@@ -64,8 +64,14 @@ struct CafFftArgs {
 
 // NLB lag blocks are accumulated per pass over the segment (U = FFT(w*ref piece) is shared by
 // them; V_l = FFT(srv piece shifted by l*lagblk)); more lag blocks than NLB repeat the pass.
+// Occupancy: with one lag block (NLB = 1: every span up to 769 lags, the headline config) the kernel does NOT load
+// ahead -- u, v and the accumulator are the only arrays live together, 163 VGPRs, three wavefronts per SIMD, and the
+// third wavefront hides the load latency better than a register-hungry prefetch did at two (config 2, MI355X, A/B
+// on one box: 2.49 -> 2.32 ms per 256 frames).  With two lag blocks per pass the prefetching form at two
+// wavefronts per SIMD stays (three would spill).
 template <bool HAS_WIN, int NLB>
-__global__ __launch_bounds__(64 * CAFF_WAVES, 2) void caf_fft_kernel(CafFftArgs a) {
+__global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_kernel(CafFftArgs a) {
+    constexpr bool PREFETCH = NLB != 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
     float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
@@ -147,21 +153,24 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, 2) void caf_fft_kernel(CafFftArgs 
                 }
             }
         };
-        issue_u(lo);
+        if (PREFETCH) issue_u(lo);
         for (int n0 = lo; n0 <= hi; n0 += B) {
             const int rem = hi - n0 + 1;
             const int cnt = rem < B ? rem : B;
             float2 u[16], v[NLB][16];
+            if (!PREFETCH) issue_u(n0);
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
-            issue_v(v[0], n0, cnt, lb0);
+            if (PREFETCH) issue_v(v[0], n0, cnt, lb0);
             __builtin_amdgcn_sched_barrier(0);
             fft1024_fwd(u, tile, tab, f);
 #pragma unroll
             for (int l = 0; l < NLB; ++l) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (l + 1 < NLB)
+                if (!PREFETCH)
+                    issue_v(v[l], n0, cnt, lb0 + l);
+                else if (l + 1 < NLB)
                     issue_v(v[l + 1 < NLB ? l + 1 : 0], n0, cnt, lb0 + l + 1);
                 else
                     issue_u(n0 + B);                        // past the last piece: zero records -> zeros

@@ -217,7 +217,7 @@ class HipBackend:
     def __init__(self, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
                  doppler_bins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), clutter="ls",
                  batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, overlap=True,
-                 ls_method=0, nsub=2):
+                 ls_method=0, nsub=2, ls_streams=2):
         import torch
         from . import engine
         from .range_doppler_processing import _named_window
@@ -238,13 +238,20 @@ class HipBackend:
         self.sub = -(-self.batch // max(int(nsub), 1)) if (self.overlap and clutter == "ls") else self.batch
         with torch.cuda.device(self.device):
             self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch, caf_method, doppler_method)
-            self.ls = engine.LsPlan(self.C, self.R, 10, False, self.sub, ls_method) if clutter == "ls" else None
+            # The LS chain of a sub-batch is a strictly sequential string of kernels, a third of them latency-bound
+            # (one Levinson-Durbin per block, per-bin solves: a few wavefronts busy).  Two plans on two streams
+            # run alternate sub-batches concurrently, so one chain's solves sit under the other's HBM-bound passes.
+            self.nls = max(1, int(ls_streams)) if (self.overlap and clutter == "ls") else 1
+            self.ls_plans = [engine.LsPlan(self.C, self.R, 10, False, self.sub, ls_method)
+                             for _ in range(self.nls)] if clutter == "ls" else []
+            self.ls = self.ls_plans[0] if self.ls_plans else None
             if isinstance(window, (tuple, str)):
                 w = _named_window(window, self.cpi)
             else:
                 w = None if window is None else np.ascontiguousarray(window, dtype=np.float32)
             self.window = None if w is None else torch.from_numpy(w).to(self.device)
-            self.s_ls = torch.cuda.Stream(device=self.device) if self.overlap else None
+            self.s_ls_all = [torch.cuda.Stream(device=self.device) for _ in range(self.nls)] if self.overlap else []
+            self.s_ls = self.s_ls_all[0] if self.s_ls_all else None
             self.s_caf = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._clean_buf = None
         self._fe_plans = {}
@@ -299,11 +306,11 @@ class HipBackend:
             out = self._clean_buf = self.torch.zeros_like(srv_pad)
         return out
 
-    def _clean_range(self, ref_pad, srv_pad, out, c0, nb, stream):
+    def _clean_range(self, ref_pad, srv_pad, out, c0, nb, stream, plan=None):
         C, off = self.C, self.C // 2 + c0 * self.C
         if self.clutter == "ls":
-            self.ls.execute(ref_pad[off:], srv_pad[off:], out[off:], nb, C, C, self.fs, self.bins, 0.0,
-                            None, stream)
+            (plan or self.ls).execute(ref_pad[off:], srv_pad[off:], out[off:], nb, C, C, self.fs, self.bins, 0.0,
+                                      None, stream)
         else:
             self.engine.nlms_execute(ref_pad[off:], srv_pad[off:], out[off:], C, self.R, self.nlms_mu, 10,
                                      None, None, nb, C, C, stream)
@@ -348,23 +355,29 @@ class HipBackend:
         if out is None:
             out = torch.empty((nframes, self.F, self.R + 1), dtype=torch.complex64, device=self.device)
         main = torch.cuda.current_stream()
-        self.s_ls.wait_stream(main)
+        for st in self.s_ls_all:
+            st.wait_stream(main)
         self.s_caf.wait_stream(main)
         first_chunk = offsets_first // self.C
         done = 0
         with torch.cuda.device(self.device):
-            for c0 in range(0, nlocal, self.sub):
+            for idx, c0 in enumerate(range(0, nlocal, self.sub)):
                 c1 = min(c0 + self.sub, nlocal)
-                self._clean_range(ref_pad, srv_pad, clean, c0, c1 - c0, ctypes.c_void_p(self.s_ls.cuda_stream))
+                k = idx % self.nls
+                st = self.s_ls_all[k]
+                self._clean_range(ref_pad, srv_pad, clean, c0, c1 - c0, ctypes.c_void_p(st.cuda_stream),
+                                  self.ls_plans[k])
                 ev = torch.cuda.Event()
-                ev.record(self.s_ls)
+                ev.record(st)
+                # the CAF stream waits for every sub-batch in order, so "chunks below c1 are clean" holds there
+                self.s_caf.wait_event(ev)
                 ready = nframes if c1 == nlocal else max(min(nframes, c1 - 1 - first_chunk), 0)
                 if ready > done:
-                    self.s_caf.wait_event(ev)
                     self.frames(ref_pad, clean, offsets_first, nframes, out, done, ready,
                                 ctypes.c_void_p(self.s_caf.cuda_stream))
                     done = ready
-        main.wait_stream(self.s_ls)
+        for st in self.s_ls_all:
+            main.wait_stream(st)
         main.wait_stream(self.s_caf)
         return out
 

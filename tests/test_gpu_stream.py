@@ -116,9 +116,11 @@ def test_pipeline_is_deterministic():
         be.overlap = overlap and True          # force the two-stream path even for this small batch
         if overlap:
             be.sub = 4
-            be.s_ls = torch.cuda.Stream()
+            be.nls = 2                                     # two LS chains in flight on two streams
+            be.s_ls_all = [torch.cuda.Stream(), torch.cuda.Stream()]
             be.s_caf = torch.cuda.Stream()
-            be.ls = be.engine.LsPlan(C, R, 10, False, 4)
+            be.ls_plans = [be.engine.LsPlan(C, R, 10, False, 4) for _ in range(2)]
+            be.ls = be.ls_plans[0]
         rp, sp_ = be.padded(ref), be.padded(srv)
         outs.append(be.run(rp, sp_, 8, 0, 8).cpu().numpy())
         torch.cuda.synchronize()
