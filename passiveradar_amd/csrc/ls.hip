@@ -280,7 +280,9 @@ struct LsPrepArgs {
     double theta0;           // rotation of the reference the autocorrelation was taken with
     double2* c0;             // [block][T]
     double2* se;             // [block][T]
-    double2* tinv;           // [block][T][T]
+    double2* tinv;           // [block][T][T] dense inverse (Trench), or nullptr: Gohberg-Semencul mode ...
+    double2* apred;          // ... [block][T] forward predictor a (a[0] = 1)
+    double* perr;            // ... [block] final prediction error
 };
 
 __global__ __launch_bounds__(LS_THREADS) void ls_prepare_kernel(LsPrepArgs a) {
@@ -349,6 +351,13 @@ __global__ __launch_bounds__(LS_THREADS) void ls_prepare_kernel(LsPrepArgs a) {
     }
     __syncthreads();
     const double2* af = scratch[0].y != 0.0 ? abuf1 : abuf0;   // forward predictor, af[0] = 1
+    if (!a.tinv) {
+        // Gohberg-Semencul mode: T_0^{-1} = (1/err) [ L(a) L(a)^H - L(z) L(z)^H ] is applied from the predictor itself
+        // (ls_solve_gs_kernel); nothing dense is built
+        for (int k = tid; k < T; k += LS_THREADS) a.apred[(int64_t)b * T + k] = af[k];
+        if (tid == 0) a.perr[b] = scratch[0].x;
+        return;
+    }
     const double ie = 1.0 / scratch[0].x;              // x = af / err is the first column of T_0^{-1}
     double2* tinv = a.tinv + (int64_t)b * T * T;
     // Trench recurrence along the diagonals of the lower triangle (i = j + d), mirrored by symmetry:
@@ -504,6 +513,234 @@ __global__ __launch_bounds__(LSS_THREADS) void ls_solve_kernel(LsSolveArgs a) {
     }
 }
 
+
+// ---- the same solve with T_0^{-1} in Gohberg-Semencul form ---------------------------------------------------
+// T_0^{-1} = (1/err) [ L(a) L(a)^H - L(z) L(z)^H ],  a = forward predictor (a[0] = 1), err = final prediction error,
+// z = (0, conj(a[T-1]), ..., conj(a[1])),  L(v) = lower-triangular Toeplitz matrix with first column v
+// (identity, the refinement behaviour and the thread mapping below are checked in tools/gs_solver_model.py).
+// A mat-vec is four triangular Toeplitz products on T-vectors that live in LDS -- 2 T^2 complex MACs in double
+// from 17 KB of LDS instead of T^2 MACs on a 1.1 MB matrix streamed from L2/HBM per mat-vec and block -- and the
+// residual against the exact Toeplitz(c_f) is two more.  Every product runs on all 1024 threads: a thread owns four
+// consecutive outputs and one slice of the lag range, slides a four-element window over a zero-padded,
+// four-way de-interleaved copy of the input (consecutive lanes read consecutive 16-byte words: no bank conflict)
+// and the slices are summed through LDS in a fixed order (deterministic).
+struct LsGsArgs {
+    const float2* partial;   // slot 1 = conj( sum_n s~[n] conj(rho[n-k]) )
+    const double2* c0;
+    const double2* se;
+    const double2* apred;    // [block][T]
+    const double* perr;      // [block]
+    const float2* ref;
+    const float2* srv;
+    int64_t ref_stride, srv_stride;
+    double2* taps;
+    double2* taps_t;
+    int64_t n;
+    int32_t nblk, T, nref, peek, srv_rotated;
+    double theta;
+    int32_t G, parts, span, Q;   // output groups of 4, lag slices, lags per slice, plane length of the padded vectors
+};
+
+struct TriTerm {
+    const double2* c;        // coefficient vector in LDS, already conjugated / reversed / negated: coef(d) = c[d]
+    const double2* pv;       // padded, de-interleaved input vector in LDS
+    int dmin;                // first lag (1 skips the diagonal)
+};
+
+__device__ __forceinline__ int gs_slot(int e, int Q) { const int ep = e + 4; return (ep & 3) * Q + (ep >> 2); }
+
+__device__ __forceinline__ void zfma(double2& acc, double2 a, double2 b) {      // acc += a * b, four FMAs
+    acc.x = fma(a.x, b.x, acc.x);
+    acc.x = fma(-a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y);
+    acc.y = fma(a.y, b.x, acc.y);
+}
+
+// acc[j] += sum_d c[d] in[o0 + j + d]  (UP, d <= T-1-o0)   or   in[o0 + j - d]  (DOWN, d <= min(o0+3, T-1)); the
+// group's OWN lag range [dmin, rmax] is cut into `parts` equal slices and this thread takes slice `c`, so no thread
+// idles on the empty half of the triangle; entries of `in` outside [0, T) are zero
+template <bool UP>
+__device__ __forceinline__ void tri_accumulate(double2 (&acc)[4], const TriTerm& k, int o0, int c, int parts, int T,
+                                               int Q) {
+    const int rmax = UP ? (T - 1 - o0) : (o0 + 3 < T - 1 ? o0 + 3 : T - 1);
+    const int len = rmax - k.dmin + 1;
+    if (len <= 0) return;
+    const int per = (len + parts - 1) / parts;
+    const int dlo = k.dmin + c * per;
+    int dhi = dlo + per - 1;
+    if (dhi > rmax) dhi = rmax;
+    if (dlo > dhi) return;
+    double2 w0, w1, w2, w3;
+    if (UP) {
+        w0 = k.pv[gs_slot(o0 + dlo, Q)];     w1 = k.pv[gs_slot(o0 + 1 + dlo, Q)];
+        w2 = k.pv[gs_slot(o0 + 2 + dlo, Q)]; w3 = k.pv[gs_slot(o0 + 3 + dlo, Q)];
+    } else {
+        w0 = k.pv[gs_slot(o0 - dlo, Q)];     w1 = k.pv[gs_slot(o0 + 1 - dlo, Q)];
+        w2 = k.pv[gs_slot(o0 + 2 - dlo, Q)]; w3 = k.pv[gs_slot(o0 + 3 - dlo, Q)];
+    }
+    for (int d = dlo; d <= dhi; ++d) {
+        const double2 co = k.c[d];
+        zfma(acc[0], co, w0);
+        zfma(acc[1], co, w1);
+        zfma(acc[2], co, w2);
+        zfma(acc[3], co, w3);
+        if (UP) {
+            w0 = w1; w1 = w2; w2 = w3;
+            w3 = k.pv[gs_slot(o0 + 4 + d, Q)];
+        } else {
+            w3 = w2; w2 = w1; w1 = w0;
+            w0 = k.pv[gs_slot(o0 - 1 - d, Q)];
+        }
+    }
+}
+
+__global__ __launch_bounds__(LSS_THREADS) void ls_solve_gs_kernel(LsGsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int T = a.T, Q = a.Q, G = a.G, parts = a.parts;
+    double2* A = reinterpret_cast<double2*>(smem_raw);    // a[d]                        (y: sum_d a[d] p[i-d])
+    double2* Ac = A + T;                                   // conj(a[d])                  (p: sum_d conj(a[d]) v[k+d])
+    double2* Ar = Ac + T;                                  // a[T-d], d >= 1              (q: sum_d a[T-d] v[k+d])
+    double2* Az = Ar + T;                                  // -conj(a[T-d]), d >= 1       (y: - sum_d conj(a[T-d]) q[i-d])
+    double2* CF = Az + T;                                  // exact first column c_f[d] of this bin
+    double2* CFc = CF + T;                                 // conj(c_f[d]), d >= 1
+    double2* bb = CFc + T;                                 // right-hand side
+    double2* dd = bb + T;                                  // D[k] = e^{j theta k}
+    double2* PVv = dd + T;                                 // D^H (rhs or residual), padded / de-interleaved (4 Q)
+    double2* PVp = PVv + 4 * Q;
+    double2* PVq = PVp + 4 * Q;
+    double2* PVx = PVq + 4 * Q;                            // solution
+    double2* pacc = PVx + 4 * Q;                           // [parts][4 G] slice sums
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int g = tid % G, c = tid / G;
+    const bool worker = c < parts;
+    const int o0 = 4 * g;
+    const float2* part_sum = a.partial + (int64_t)b * a.nblk * 2 * T;
+    const double ierr = 1.0 / a.perr[b];
+    const double gx = cos(-a.theta * (double)a.n) - 1.0, gy = sin(-a.theta * (double)a.n);
+    for (int i = tid; i < 16 * Q; i += LSS_THREADS) PVv[i] = make_double2(0.0, 0.0);   // the four padded vectors
+    // Set-up, arranged for latency (this kernel is one workgroup per block, a few microseconds of arithmetic: what
+    // it waits for is global memory): the per-wave partial sums are reduced by all threads (S slices of the slot
+    // range per lag, the loads of a slice independent of each other) and the <= 2 peek wrapped samples behind
+    // E_b are staged through LDS in ONE round trip instead of being walked by ten threads one sample at a time.
+    const int S = (LSS_THREADS / T) < 1 ? 1 : ((LSS_THREADS / T) > 8 ? 8 : (LSS_THREADS / T));
+    const int per = (a.nblk + S - 1) / S;
+    if (tid < S * T) {
+        const int k = tid % T, sl = tid / T;
+        const int b0 = sl * per, b1 = (b0 + per < a.nblk) ? b0 + per : a.nblk;
+        double br = 0, bi = 0;
+#pragma unroll 8
+        for (int blk = b0; blk < b1; ++blk) {
+            const float2 u = part_sum[((int64_t)blk * 2 + 1) * T + k];
+            br += (double)u.x;
+            bi += (double)u.y;
+        }
+        pacc[sl * T + k] = make_double2(br, bi);
+    }
+    double2* stg_r = pacc + (size_t)parts * 4 * G;         // conj(ref[i]),            i < peek
+    double2* stg_s = stg_r + a.peek;                       // s~[n - peek + i],        i < peek
+    if (a.theta != 0.0 && tid < 2 * a.peek) {
+        if (tid < a.peek) {
+            const float2 r = (a.ref + (int64_t)b * a.ref_stride)[tid];
+            stg_r[tid] = make_double2(r.x, -r.y);
+        } else {
+            const int i = tid - a.peek;
+            const int64_t j = a.n - a.peek + i;            // sample index; s~[j] = s[j] e^{-j theta (j + peek)}
+            const float2 sraw = (a.srv + (int64_t)b * a.srv_stride)[j];
+            double2 st = make_double2(sraw.x, sraw.y);
+            if (!a.srv_rotated) {
+                double s2, c2;
+                sincos(-a.theta * (double)(j + a.peek), &s2, &c2);
+                st = zmul(st, make_double2(c2, s2));
+            }
+            stg_s[i] = st;
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < T; k += LSS_THREADS) {
+        double br = 0, bi = 0;
+        for (int sl = 0; sl < S; ++sl) { br += pacc[sl * T + k].x; bi += pacc[sl * T + k].y; }
+        double sn, cs;
+        sincos(a.theta * (double)k, &sn, &cs);
+        const double2 D = make_double2(cs, sn);
+        // b_f[k] = e^{j theta k} ( B~[k] + (conj(gamma)-1) E_b[k] ),
+        // E_b[k] = sum_{i=0}^{peek-1-k} conj(ref[i]) s~[n - peek + i + k]      (see ls_solve_kernel)
+        double2 eb = make_double2(0, 0);
+        if (a.theta != 0.0 && k < a.peek)
+            for (int i = 0; i + k < a.peek; ++i) eb = zadd(eb, zmul(stg_r[i], stg_s[i + k]));
+        const double2 rhs = zmul(D, zadd(make_double2(br, -bi), zmul(make_double2(gx, -gy), eb)));
+        bb[k] = rhs;
+        dd[k] = D;
+        PVv[gs_slot(k, Q)] = zmul(zconj(D), rhs);
+        const double2 base = zadd(a.c0[(int64_t)b * T + k], zmul(make_double2(gx, gy), a.se[(int64_t)b * T + k]));
+        const double2 cfk = zmul(D, base);
+        CF[k] = cfk;
+        CFc[k] = zconj(cfk);
+        const double2 ak = a.apred[(int64_t)b * T + k];
+        A[k] = ak;
+        Ac[k] = zconj(ak);
+        const double2 arev = k >= 1 ? a.apred[(int64_t)b * T + (T - k)] : make_double2(0.0, 0.0);   // a[T-d]
+        Ar[k] = arev;
+        Az[k] = make_double2(-arev.x, arev.y);
+    }
+    __syncthreads();
+    // one product: every worker accumulates its slice, the slices are summed per output
+    auto product = [&](const TriTerm& t0, bool up0, const TriTerm* t1, bool up1) -> double2 {
+        if (worker) {
+            double2 acc[4] = {make_double2(0, 0), make_double2(0, 0), make_double2(0, 0), make_double2(0, 0)};
+            if (up0) tri_accumulate<true>(acc, t0, o0, c, parts, T, Q);
+            else tri_accumulate<false>(acc, t0, o0, c, parts, T, Q);
+            if (t1) {
+                if (up1) tri_accumulate<true>(acc, *t1, o0, c, parts, T, Q);
+                else tri_accumulate<false>(acc, *t1, o0, c, parts, T, Q);
+            }
+            double2* pa = pacc + (size_t)c * 4 * G + o0;
+            pa[0] = acc[0]; pa[1] = acc[1]; pa[2] = acc[2]; pa[3] = acc[3];
+        }
+        __syncthreads();
+        double2 sum = make_double2(0, 0);
+        if (tid < T)
+            for (int q = 0; q < parts; ++q) sum = zadd(sum, pacc[(size_t)q * 4 * G + tid]);
+        return sum;                                        // caller stores, then __syncthreads()
+    };
+    for (int it = 0; it <= a.nref; ++it) {
+        // x (+)= D T_0^{-1} v,   T_0^{-1} v = ( L(a) [L(a)^H v] - L(z) [L(z)^H v] ) / err
+        {
+            const TriTerm tp = {Ac, PVv, 0};                                // p[k] = sum_d conj(a[d]) v[k+d]
+            const double2 pk = product(tp, true, nullptr, false);
+            if (tid < T) PVp[gs_slot(tid, Q)] = pk;
+            __syncthreads();
+            const TriTerm tq = {Ar, PVv, 1};                                // q[k] = sum_{d>=1} a[T-d] v[k+d]
+            const double2 qk = product(tq, true, nullptr, false);
+            if (tid < T) PVq[gs_slot(tid, Q)] = qk;
+            __syncthreads();
+            const TriTerm ty0 = {A, PVp, 0};                                // sum_d a[d] p[i-d]
+            const TriTerm ty1 = {Az, PVq, 1};                               // - sum_{d>=1} conj(a[T-d]) q[i-d]
+            const double2 yk = product(ty0, false, &ty1, false);
+            if (tid < T) {
+                const double2 acc = zmul(dd[tid], zscale(yk, ierr));
+                const int sl = gs_slot(tid, Q);
+                PVx[sl] = it == 0 ? acc : zadd(PVx[sl], acc);
+            }
+            __syncthreads();
+        }
+        if (it == a.nref) break;
+        // residual against the exact Toeplitz(c_f):  v = D^H ( b - T_f x ),  (T_f x)[i] = sum_{d<=i} c_f[d] x[i-d] +
+        // sum_{d>=1} conj(c_f[d]) x[i+d]
+        {
+            const TriTerm tr0 = {CF, PVx, 0};
+            const TriTerm tr1 = {CFc, PVx, 1};
+            const double2 tx = product(tr0, false, &tr1, true);
+            if (tid < T) PVv[gs_slot(tid, Q)] = zmul(zconj(dd[tid]), zsub(bb[tid], tx));
+            __syncthreads();
+        }
+    }
+    for (int k = tid; k < T; k += LSS_THREADS) {
+        const double2 xk = PVx[gs_slot(k, Q)];
+        a.taps[(int64_t)b * T + k] = xk;
+        a.taps_t[(int64_t)b * T + k] = zmul(xk, zconj(dd[k]));
+    }
+}
+
 // ---- FIR apply: out[n] = s[n] - sum_k w[k] r[n-k] ----------------------------------------
 #define FIR_OPT 4
 #define FIR_SPAN (LS_THREADS * FIR_OPT)
@@ -579,7 +816,12 @@ struct prc_ls_plan {
     // shared-inverse path (non-circular FFT chain): c_0, S_e, dense T_0^{-1} per block
     double2* d_c0 = nullptr;
     double2* d_se = nullptr;
-    double2* d_tinv = nullptr;
+    double2* d_tinv = nullptr;      // dense T_0^{-1} per block (Trench) -- only when the Gohberg-Semencul form does not fit LDS
+    double2* d_apred = nullptr;     // Gohberg-Semencul form: forward predictor per block ...
+    double* d_perr = nullptr;       // ... and its final prediction error
+    bool chain = false;             // shared-inverse chain available (non-circular 1024-point FFT kernels)
+    int gs_G = 0, gs_parts = 0, gs_span = 0, gs_Q = 0;
+    size_t gs_lds = 0;
     double2* d_taps_t = nullptr;   // w~ per block
     float2* d_cache = nullptr;     // FFT(rho block) per piece, reused by every bin
     // optional per-kernel timing (bench.py roofline): events around every launch of one execute
@@ -599,6 +841,8 @@ extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
     if (p->d_c0) (void)hipFree(p->d_c0);
     if (p->d_se) (void)hipFree(p->d_se);
     if (p->d_tinv) (void)hipFree(p->d_tinv);
+    if (p->d_apred) (void)hipFree(p->d_apred);
+    if (p->d_perr) (void)hipFree(p->d_perr);
     if (p->d_taps_t) (void)hipFree(p->d_taps_t);
     if (p->d_cache) (void)hipFree(p->d_cache);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
@@ -642,7 +886,26 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     if (e == hipSuccess && p->method == 2 && !d->circular && !p->team) {
         e = hipMalloc(&p->d_c0, sizeof(double2) * (size_t)d->max_blocks * T);
         if (e == hipSuccess) e = hipMalloc(&p->d_se, sizeof(double2) * (size_t)d->max_blocks * T);
-        if (e == hipSuccess) e = hipMalloc(&p->d_tinv, sizeof(double2) * (size_t)d->max_blocks * T * T);
+        p->chain = true;
+        // T_0^{-1} in Gohberg-Semencul form when its vectors fit the CU's LDS (they do up to the 769 taps of these
+        // kernels); the dense Trench inverse is the fallback
+        p->gs_G = (T + 3) / 4;
+        p->gs_parts = LSS_THREADS / p->gs_G;
+        if (p->gs_parts > 16) p->gs_parts = 16;
+        if (p->gs_parts < 1) p->gs_parts = 1;
+        p->gs_span = (T + p->gs_parts - 1) / p->gs_parts;
+        p->gs_Q = (T + 8 + 3) / 4;
+        p->gs_lds = sizeof(double2) * ((size_t)8 * T + 16 * (size_t)p->gs_Q +
+                                       (size_t)p->gs_parts * 4 * p->gs_G + 2 * (size_t)d->peek);
+        const bool use_gs = p->gs_lds <= 160 * 1024 && p->gs_G <= LSS_THREADS;
+        if (use_gs) {
+            if (e == hipSuccess) e = hipMalloc(&p->d_apred, sizeof(double2) * (size_t)d->max_blocks * T);
+            if (e == hipSuccess) e = hipMalloc(&p->d_perr, sizeof(double) * (size_t)d->max_blocks);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)ls_solve_gs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        } else if (e == hipSuccess) {
+            e = hipMalloc(&p->d_tinv, sizeof(double2) * (size_t)d->max_blocks * T * T);
+        }
         if (e == hipSuccess) e = hipMalloc(&p->d_taps_t, sizeof(double2) * (size_t)d->max_blocks * T);
         // auto / method 3: keep FFT(rho block) in an HBM spectrum cache instead of recomputing it per
         // bin (measured: the fused kernel is HBM-bound at 2 FFTs per block and VALU-bound at 3).  If the
@@ -735,7 +998,18 @@ static int run_cached_chain(prc_ls_plan* p, const void* ref, const void* srv, in
         const double est = pr.enabled ? gm1 * 10.0 * (double)p->desc.peek / (double)n : 0.0;
         sa.nref = 0;
         for (double left = est; left > 1e-9 && sa.nref < 4; left *= est) ++sa.nref;
-        hipLaunchKernelGGL(ls_solve_kernel, dim3(nblocks), dim3(LSS_THREADS), solve_lds, stream, sa);
+        if (p->d_apred) {
+            LsGsArgs ga;
+            ga.partial = sa.partial;  ga.c0 = sa.c0;  ga.se = sa.se;  ga.apred = p->d_apred;  ga.perr = p->d_perr;
+            ga.ref = sa.ref;  ga.srv = sa.srv;  ga.ref_stride = sa.ref_stride;  ga.srv_stride = sa.srv_stride;
+            ga.taps = sa.taps;  ga.taps_t = sa.taps_t;
+            ga.n = n;  ga.nblk = sa.nblk;  ga.T = T;  ga.nref = sa.nref;  ga.peek = sa.peek;
+            ga.srv_rotated = sa.srv_rotated;  ga.theta = sa.theta;
+            ga.G = p->gs_G;  ga.parts = p->gs_parts;  ga.span = p->gs_span;  ga.Q = p->gs_Q;
+            hipLaunchKernelGGL(ls_solve_gs_kernel, dim3(nblocks), dim3(LSS_THREADS), p->gs_lds, stream, ga);
+        } else {
+            hipLaunchKernelGGL(ls_solve_kernel, dim3(nblocks), dim3(LSS_THREADS), solve_lds, stream, sa);
+        }
         PRC_LAUNCH_CHECK();
         return PRC_OK;
     };
@@ -754,7 +1028,7 @@ static int run_cached_chain(prc_ls_plan* p, const void* ref, const void* srv, in
         pa.partial = p->d_partial;  pa.ref = (const float2*)ref;  pa.ref_stride = stride;
         pa.n = n;  pa.nblk = p->nblk;  pa.T = T;  pa.peek = p->desc.peek;  pa.reg = reg;
         pa.theta0 = 0.0;                // the chain correlates the unrotated reference
-        pa.c0 = p->d_c0;  pa.se = p->d_se;  pa.tinv = p->d_tinv;
+        pa.c0 = p->d_c0;  pa.se = p->d_se;  pa.tinv = p->d_tinv;  pa.apred = p->d_apred;  pa.perr = p->d_perr;
         hipLaunchKernelGGL(ls_prepare_kernel, dim3(nblocks), dim3(LS_THREADS),
                            sizeof(double2) * ((size_t)3 * T + 1), stream, pa);
         PRC_LAUNCH_CHECK();
@@ -824,7 +1098,7 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
     // The cached chain needs the wrap perturbation (gamma-1) S_e to be small against c_0 for the
     // refinement to converge fast (ratio ~ peek/N); short blocks and single-bin calls keep the
     // per-bin Levinson solve.
-    p->last_cached = p->d_tinv && nbins > 1 && n >= 2000LL * (p->desc.peek > 0 ? p->desc.peek : 1);
+    p->last_cached = p->chain && nbins > 1 && n >= 2000LL * (p->desc.peek > 0 ? p->desc.peek : 1);
     if (p->last_cached) {
         int rc = run_cached_chain(p, ref, srv, stride, out, out_stride, nblocks, sample_rate, bins, nbins, reg,
                                   stream);

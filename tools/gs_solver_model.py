@@ -88,3 +88,81 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---- thread-level model of ls_solve_gs_kernel's triangular Toeplitz products (csrc/ls.hip) ------------------------
+def _tri_model(T, terms, threads=1024):
+    """terms: list of (up, c, rev, conj, sign, dmin, vec).  Returns out[o] = sum over terms of
+         up  : sum_{d=dmin}^{T-1-o} coef(d) vec[o+d]        down: sum_{d=dmin}^{o} coef(d) vec[o-d]
+       computed the way the kernel does: groups of 4 consecutive outputs per thread, the group's own lag range cut into
+       `parts` equal slices, sliding 4-element window over a zero-padded, 4-way de-interleaved copy of vec, partial
+       sums per slice."""
+    G = (T + 3) // 4
+    parts = max(1, min(threads // G, 16))
+    Q = (T + 8 + 3) // 4
+
+    def plane(vec):
+        pv = np.zeros(4 * Q, complex)
+        for e in range(T):
+            ep = e + 4
+            pv[(ep & 3) * Q + (ep >> 2)] = vec[e]
+        return pv
+
+    def rd(pv, e):
+        ep = e + 4
+        assert 0 <= ep < T + 8, e
+        return pv[(ep & 3) * Q + (ep >> 2)]
+
+    pacc = np.zeros((parts, 4 * G), complex)
+    for c in range(parts):
+        for g in range(G):
+            o0 = 4 * g
+            acc = np.zeros(4, complex)
+            for up, cv, rev, cj, sign, dmin, vec in terms:
+                pv = plane(vec)
+                rmax = (T - 1 - o0) if up else min(o0 + 3, T - 1)
+                ln = rmax - dmin + 1
+                if ln <= 0:
+                    continue
+                per = -(-ln // parts)
+                dlo = dmin + c * per
+                dhi = min(dlo + per - 1, rmax)
+                if dlo > dhi:
+                    continue
+                w = [rd(pv, o0 + j + dlo) if up else rd(pv, o0 + j - dlo) for j in range(4)]
+                for d in range(dlo, dhi + 1):
+                    co = cv[T - d] if rev else cv[d]
+                    co = (np.conj(co) if cj else co) * sign
+                    for j in range(4):
+                        acc[j] += co * w[j]
+                    if up:
+                        w = w[1:] + [rd(pv, o0 + 3 + d + 1)]
+                    else:
+                        w = [rd(pv, o0 - (d + 1))] + w[:3]
+            pacc[c, o0:o0 + 4] = acc
+    return pacc.sum(axis=0)[:T]
+
+
+def check_kernel_mapping():
+    rng = np.random.default_rng(5)
+    for T in (50, 266, 267):
+        a = rng.standard_normal(T + 1) + 1j * rng.standard_normal(T + 1)   # a[T] is never read (rev needs d >= 1)
+        a = a[:T]
+        apad = np.concatenate((a, [0]))
+        v = rng.standard_normal(T) + 1j * rng.standard_normal(T)
+        p = _tri_model(T, [(True, apad, False, True, 1.0, 0, v)])
+        q = _tri_model(T, [(True, apad, True, False, 1.0, 1, v)])
+        y = _tri_model(T, [(False, apad, False, False, 1.0, 0, p), (False, apad, True, True, -1.0, 1, q)])
+        ref = gs_apply(a, 1.0, v)
+        e1 = np.abs(y - ref).max() / np.abs(ref).max()
+        cf = rng.standard_normal(T) + 1j * rng.standard_normal(T); cf[0] = cf[0].real
+        Tf = np.array([[cf[i - j] if i >= j else np.conj(cf[j - i]) for j in range(T)] for i in range(T)])
+        cfp = np.concatenate((cf, [0]))
+        r = _tri_model(T, [(False, cfp, False, False, 1.0, 0, v), (True, cfp, False, True, 1.0, 1, v)])
+        e2 = np.abs(r - Tf @ v).max() / np.abs(Tf @ v).max()
+        print(f"(5) kernel mapping T={T}: G-S mat-vec {e1:.1e}, Hermitian Toeplitz product {e2:.1e}")
+        assert e1 < 1e-12 and e2 < 1e-12
+
+
+if __name__ == "__main__":
+    check_kernel_mapping()
