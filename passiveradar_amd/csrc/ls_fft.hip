@@ -617,9 +617,10 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_cached_kernel(LsFft
 // wave reads X_p (cache) and the surveillance piece once, writes the cleaned piece once and keeps it
 // in registers as the input of the next bin's correlation -- 20 KB of HBM traffic per 1025-T
 // samples per bin instead of 34 KB for the two separate kernels.
-// CACHED: X_p = FFT(rho block p) is read from the spectrum cache (8 KB per block).  !CACHED: it is
-// recomputed from the reference (6 KB per block + L2-served overlap, one more FFT): fewer HBM bytes,
-// more VALU -- the kernel is HBM-bound, so this is the default.
+// CACHED (the default, prc_ls_desc.method 0 / 3): X_p = FFT(rho block p) is read from the spectrum cache (8 KB
+// per block).  !CACHED (method 2, or when the cache does not fit): it is recomputed from the reference (6 KB per
+// block + L2-served overlap, one more FFT): fewer HBM bytes but a third transform, which makes the kernel
+// VALU-bound -- measured slower than the HBM-bound cached form.
 template <bool CACHED, bool ROT_IN>
 __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

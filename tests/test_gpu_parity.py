@@ -541,9 +541,13 @@ def test_nlms_full_cfg3_hop_vs_c_oracle():
     exp, etaps = c_oracle.nlms(ref, srv, L, 0.02, 10)
     t1 = time.time()
     out, taps = NLMS_filter(ref, srv, L, 0.02, 10, None, True)
-    print(f"C twin {t1 - t0:.1f}s, device {time.time() - t1:.1f}s")
-    assert rel_err(out, exp) < TOL and rel_err(taps, etaps) < TOL
-    assert rel_err(out[-50000:], exp[-50000:]) < TOL          # no drift at the far end either
+    # the far end against the SAME scale (the converged residual is ~100x below the stream's peak: its own peak
+    # would turn the float32 floor of two summation orders, 2e-5 of the stream, into 1.5e-3)
+    e_out, e_taps = rel_err(out, exp), rel_err(taps, etaps)
+    e_end = float(np.abs(out[-50000:] - exp[-50000:]).max() / np.abs(exp).max())
+    print(f"C twin {t1 - t0:.1f}s, device {time.time() - t1:.1f}s; errors out {e_out:.2e} taps {e_taps:.2e} last-50k {e_end:.2e}")
+    assert e_out < TOL and e_taps < TOL, (e_out, e_taps, e_end)
+    assert e_end < TOL                                        # no drift at the far end either
 
 
 def test_nlms_reference_level_step():

@@ -131,6 +131,48 @@ def test_output_store_roundtrip(tmp_path):
     assert m["frame_timestamps"].shape == (5,) and m["range_bins"].shape == (4,) and m["doppler_bins"].shape == (16,)
 
 
+def test_zarr_store_follows_the_v2_specification(tmp_path):
+    """zarr is not installed here, so the store is held against the v2 storage specification: required .zarray keys
+    and types, chunk grid / file names / in-chunk order through a reader written from the spec (which also reads
+    layouts the writer never produces), the format dispatch of main.py:208-227."""
+    from passiveradar_amd import output
+    rng = np.random.default_rng(8)
+    frames = (rng.standard_normal((3, 6, 5)) + 1j * rng.standard_normal((3, 6, 5))).astype(np.complex64)
+    cfg = dict(range_doppler_map_ftype="zarr", range_doppler_map_fname=str(tmp_path / "X.zarr"))
+    p = output.save_range_doppler(cfg, frames)
+    meta = json.load(open(os.path.join(p, ".zarray")))
+    assert output.validate_zarr_v2_metadata(meta) == np.dtype("<c8")
+    assert sorted(os.listdir(p)) == [".zarray", ".zattrs", "0.0.0", "0.0.1", "0.0.2"]
+    assert np.array_equal(output.read_zarr_v2(p), np.moveaxis(frames, 0, 2))
+    # the reader is generic: a hand-made store with a ragged 2 x 3 chunk grid, F order, '/' separator, a missing chunk
+    q = tmp_path / "other.zarr"
+    os.makedirs(q / "0")
+    os.makedirs(q / "1")
+    full = np.arange(5 * 7, dtype="<i4").reshape(5, 7)
+    json.dump({"zarr_format": 2, "shape": [5, 7], "chunks": [3, 3], "dtype": "<i4", "compressor": None,
+               "fill_value": -1, "order": "F", "filters": None, "dimension_separator": "/"}, open(q / ".zarray", "w"))
+    for i in range(2):
+        for j in range(3):
+            if (i, j) == (1, 1):
+                continue
+            blk = np.full((3, 3), 99, dtype="<i4")
+            part = full[3 * i:3 * i + 3, 3 * j:3 * j + 3]
+            blk[:part.shape[0], :part.shape[1]] = part
+            blk.ravel(order="F").tofile(q / str(i) / str(j))
+    want = full.copy()
+    want[3:5, 3:6] = -1
+    assert np.array_equal(output.read_zarr_v2(str(q)), want)
+    # spec violations are caught
+    for bad in ({**meta, "zarr_format": 3}, {k: v for k, v in meta.items() if k != "filters"}, {**meta, "chunks": [6, 5]},
+                {**meta, "dtype": "c8"}, {**meta, "order": "K"}, {**meta, "fill_value": 0.0}):
+        with pytest.raises(ValueError):
+            output.validate_zarr_v2_metadata(bad)
+    with pytest.raises(NotImplementedError):
+        output.save_range_doppler({**cfg, "range_doppler_map_ftype": "hdf5"}, frames)
+    with pytest.raises(ValueError):
+        output.save_range_doppler({**cfg, "range_doppler_map_ftype": "npy"}, frames)
+
+
 def test_iir_decimator_design_matches_scipy():
     """host-side filter design handed to prc_channel_offset / prc_decimate_iir (no device call)"""
     import scipy.signal as sg

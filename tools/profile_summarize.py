@@ -5,59 +5,64 @@
 Counter handling follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE come from separate --pmc
 passes, are reported in KB, and FETCH_SIZE is doubled on gfx950 (128-B requests tallied at 64 B); the doubling is
 re-checked against a kernel whose read volume is known (the fused LS kernel: 13.0 MB cache + 9.6 MB chunk)."""
-import csv, json, os, shutil, sys
+import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(REPO, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(REPO, "profiles")
 line = open(os.path.join(src, "bench_line.json")).read().strip()
 bench = json.loads(line)
-rows = list(csv.DictReader(open(os.path.join(src, "trace", "bench_kernel_stats.csv"))))
-shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_cfg2_kernel_stats.csv"))
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+rows = list(csv.DictReader(open(stats)))
+shutil.copy(stats, os.path.join(dst, f"{tag}_bench_cfg2_kernel_stats.csv"))
 full = os.path.join(src, "bench_full_line.json")       # the untraced default run (with the CPU baseline), if collected
 json.dump(json.loads(open(full).read()) if os.path.exists(full) else bench,
           open(os.path.join(dst, f"{tag}_bench_default.json"), "w"), indent=1)
 
-PMC_FRAMES, NSUB_UNITS = 64, 64          # the PMC passes run --frames 64: one LS launch covers 64 hop chunks
+PMC_UNITS = 64          # the PMC passes run --frames 64: one launch covers 64 hop chunks / 64 frames
+
+
 def pmc(counter):
     acc = defaultdict(list)
-    for r in csv.DictReader(open(os.path.join(src, f"pmc_{counter}", "pmc_counter_collection.csv"))):
+    f = glob.glob(os.path.join(src, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)[0]
+    for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}      # KB per launch
+
+
 fetch, write = pmc("FETCH_SIZE"), pmc("WRITE_SIZE")
 short = lambda n: n.replace("void ", "").split("(")[0]
-units = {"ls_corr_cached_kernel": NSUB_UNITS, "ls_prepare_kernel": NSUB_UNITS, "ls_solve_kernel": NSUB_UNITS,
-         "ls_fused_cached_kernel<true>": NSUB_UNITS, "caf_fft_kernel<true, 1>": PMC_FRAMES,
-         "transpose_jk_kj_kernel": PMC_FRAMES, "shift_transpose_kernel": PMC_FRAMES}
+families = {"ls_fir_subtract": "ls_fused_cached_kernel", "ls_correlate": "ls_corr_cached_kernel",
+            "ls_solve": "ls_solve_gs_kernel", "ls_prepare": "ls_prepare_kernel", "caf_segments": "caf_fft_kernel",
+            "transpose": "transpose_jk_kj_kernel", "shift": "shift_transpose_kernel"}
 traffic = {}
-for k in fetch:
-    s = short(k)
-    if s in units:
-        f_mb, w_mb = fetch[k] / 1e3 / units[s], write.get(k, 0.0) / 1e3 / units[s]
-        traffic[s] = (f_mb, w_mb, 2 * f_mb + w_mb)
-rocfft = [k for k in fetch if k.startswith("fft_")]
+for name, prefix in families.items():
+    ks = [k for k in fetch if short(k).startswith(prefix)]
+    if ks:
+        f_mb = sum(fetch[k] for k in ks) / len(ks) / 1e3 / PMC_UNITS
+        w_mb = sum(write.get(k, 0.0) for k in ks) / len(ks) / 1e3 / PMC_UNITS
+        traffic[name] = (f_mb, w_mb, 2 * f_mb + w_mb)
 C = 1200000
-calib = traffic["ls_fused_cached_kernel<true>"][0] * 2 / ((13.0e6 + 8.0 * C) / 1e6)
+calib = traffic["ls_fir_subtract"][0] * 2 / ((13.0e6 + 8.0 * C) / 1e6)
 
-name_map = {"caf_segments": "caf_fft_kernel<true, 1>", "ls_correlate": "ls_corr_cached_kernel",
-            "ls_fir_subtract": "ls_fused_cached_kernel<true>", "ls_solve": "ls_solve_kernel"}
 with open(os.path.join(dst, f"{tag}_bench_cfg2_kernel_stats.md"), "w") as f:
-    f.write(f"# Round {tag[1:].lstrip('0') or '0'} -- rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu   (default: cfg2, 256 frames/step)\n\n")
-    f.write("MI355X, N=2.4e6, R=256, F=512, LS x5 bins (T=266).  With 256 frames/step the LS chain runs as two sub-batches of 128 hop chunks on one\n"
-            "stream and the CAF of the finished frames on a second stream, so CAF launches overlap LS launches (their wall durations are inflated by sharing;\n"
+    f.write(f"# Round {tag[1:].lstrip('0') or '0'} -- rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu   "
+            f"(default: cfg2, {bench['config']['frames_per_gpu_per_step']} frames/step in sub-batches of 256)\n\n")
+    f.write("MI355X, N=2.4e6, R=256, F=512, LS x5 bins (T=266).  Per 256-frame sub-batch the LS chain runs as two launches of 128 hop chunks on two\n"
+            "streams and the CAF of the finished frames on a third, so launches overlap (their wall durations are inflated by sharing;\n"
             f"bench.py times each kernel alone).  Full CSV: profiles/{tag}_bench_cfg2_kernel_stats.csv.  Collected by tools/profile_round.sh, summarised by\n"
             "tools/profile_summarize.py.\n\n| kernel | calls | avg us / launch | % of GPU time |\n|---|---|---|---|\n")
-    for r in rows[:10]:
+    for r in rows[:12]:
         f.write(f"| {short(r['Name'])[:60]} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} |\n")
     f.write("\nbench.py per-kernel HIP-event timings of the same run (each kernel alone on the stream):\n\n"
             "| bench name | avg ms / launch | launches / step | algorithmic GB/s |\n|---|---|---|---|\n")
     for k, v in bench["kernels"].items():
-        f.write(f"| {k} | {v['avg_ms_per_launch']:.4f} | {v['launches_per_step']} | {v['algorithmic_GBps']:.0f} |\n")
+        f.write(f"| {k} | {v['avg_ms_per_launch']:.4f} | {v['launches_per_step']} | {v.get('algorithmic_GBps', 0):.0f} |\n")
     dom = bench["roofline"]["kernel"]
-    rp = [r for r in rows if short(r["Name"]) == name_map.get(dom, dom)]
+    rp = [r for r in rows if short(r["Name"]).startswith(families.get(dom, dom))]
     if rp:
         f.write(f"\nDominant kernel `{dom}`: rocprof avg {float(rp[0]['AverageNs']) / 1e6:.4f} ms vs bench "
                 f"{bench['kernels'][dom]['avg_ms_per_launch']:.4f} ms per launch (128 chunks).\n")
@@ -65,17 +70,19 @@ with open(os.path.join(dst, f"{tag}_bench_cfg2_kernel_stats.md"), "w") as f:
     f.write("## PMC passes (separate runs: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, bench.py --frames 64), raw counter KB per launch / units per launch -> MB per unit\n\n"
             "| kernel | FETCH_SIZE raw (MB/unit) | WRITE_SIZE (MB/unit) | traffic = 2*FETCH + WRITE (MB/unit) |\n|---|---|---|---|\n")
     for s, (a, b, c) in traffic.items():
-        f.write(f"| {s} | {a:.2f} | {b:.2f} | {c:.1f} |\n")
+        f.write(f"| {s} ({families[s]}) | {a:.2f} | {b:.2f} | {c:.1f} |\n")
     f.write(f"\nFETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of coalesced streaming reads); calibration: the fused kernel must read\n"
             f"the 13.0 MB spectrum cache + the 9.6 MB surveillance chunk = 22.6 MB per chunk-bin; doubled counter / expected = {calib:.3f}.\n")
-json.dump({"_note": "HBM traffic per processed unit (one hop chunk for ls_*, one frame for caf_*) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                    f"(separate passes, bench.py --frames 64, round {tag}). FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for coalesced streaming "
-                    f"reads on gfx950 (calibration on ls_fused_cached_kernel's known 22.6 MB read: doubled/expected = {calib:.3f}); WRITE_SIZE as reported. "
-                    "bench.py multiplies by the units per launch.",
-           "cfg2": {"ls_fir_subtract": round(traffic["ls_fused_cached_kernel<true>"][2] * 1e6, -4),
-                    "ls_correlate": round(traffic["ls_corr_cached_kernel"][2] * 1e6, -4),
-                    "ls_solve": round(traffic["ls_solve_kernel"][2] * 1e6, -4),
-                    "caf_segments": round(traffic["caf_fft_kernel<true, 1>"][2] * 1e6, -4),
-                    "caf_doppler": round((traffic["transpose_jk_kj_kernel"][2] + traffic["shift_transpose_kernel"][2]) * 1e6, -4)}},
+note = ("HBM traffic per processed unit (one hop chunk for ls_*, one frame for caf_*) from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+        f"(separate passes, bench.py --frames 64, round {tag}). FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for coalesced streaming "
+        f"reads on gfx950 (calibration on ls_fused_cached_kernel's known 22.6 MB read: doubled/expected = {calib:.3f}); WRITE_SIZE as reported. "
+        "bench.py multiplies by the units per launch.")
+cfg2 = {k: round(traffic[k][2] * 1e6, -4) for k in ("ls_fir_subtract", "ls_correlate", "ls_solve", "caf_segments") if k in traffic}
+if "transpose" in traffic and "shift" in traffic:
+    cfg2["caf_doppler"] = round((traffic["transpose"][2] + traffic["shift"][2]) * 1e6, -4)
+json.dump({"_note": note,
+           "_source": f"profiles/{tag}_bench_cfg2_kernel_stats.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --frames 64`, "
+                      f"round {tag}; not measured by the run that prints this line)",
+           "cfg2": cfg2},
           open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_bench_cfg2_kernel_stats.md")).read()[:3500])
