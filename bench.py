@@ -305,18 +305,31 @@ def main():
                 pending[k][1].wait()
                 pending[k] = None
 
-    outs = [torch.empty((max(nframes, 1), F, R + 1), dtype=torch.complex64, device=device) for _ in refs]
+    # map buffers: two sets used alternately when the maps are gathered, so that a step never overwrites frames a
+    # gather of the previous step may still be reading
+    nsets = 2 if gather_mode != "none" else 1
+    outs = [[torch.empty((max(nframes, 1), F, R + 1), dtype=torch.complex64, device=device) for _ in refs]
+            for _ in range(nsets)]
+    gathered = [None] * nsets                        # event: the gathers that read set p have been enqueued and done
+    stepno = [0]
 
     def step():
-        for r_i, out in zip(refs, outs):             # further illuminators share the surveillance channel
+        p = stepno[0] % nsets
+        stepno[0] += 1
+        if gathered[p] is not None:
+            torch.cuda.current_stream().wait_event(gathered[p])
+        for r_i, out in zip(refs, outs[p]):          # further illuminators share the surveillance channel
             if nframes:
                 be.run(r_i, srv_pad, nlocal, first, nframes, out=out)
         if gather_mode != "none":
             if strong:
-                gather(outs[0][:nframes])
+                gather(outs[p][0][:nframes])
             else:
                 for f0 in range(0, nframes, gsize):
-                    gather(outs[0][f0:f0 + gsize])
+                    gather(outs[p][0][f0:f0 + gsize])
+            ev_g = torch.cuda.Event()
+            ev_g.record(s_comm)
+            gathered[p] = ev_g
 
     def fence():
         drain()
@@ -359,7 +372,7 @@ def main():
         kt = {}
         ref0 = refs[0]
         clean = be.clean(ref0, srv_pad, min(nlocal, nb + 1))
-        out = outs[0]
+        out = outs[0][0]
         s = _lib.torch_stream_ptr()
         e0, e1, e2 = [], [], []
         for _ in range(reps):

@@ -84,8 +84,15 @@ class FrameComm:
     def from_torch_distributed(cls, group=None):
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except Exception as e:              # noqa: BLE001 -- every rank must still take part in the broadcast
+                box[0] = e
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if not isinstance(box[0], (bytes, bytearray)):
+            raise RuntimeError(f"rank 0 could not make an RCCL id: {box[0]}")
         return cls(rank, world, box[0])
 
     def gather(self, send, frames_per_rank, frame_elems, recv, root=0, stream=None):

@@ -2,7 +2,7 @@
 kernels switch on (FFT vs direct CAF, lag blocking, cached vs per-bin LS chain, NLMS taps-per-lane buckets)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "tests")   # run from the repo root: python tests/fuzz_parity.py [seed] [seconds] [threads]
+sys.path.insert(0, "."); sys.path.insert(0, "tests")   # run from the repo root: python tests/fuzz_parity.py [seed] [seconds] [threads] [log.md]
 from oracle import np_oracle as O, c_oracle
 from passiveradar_amd import scene
 from passiveradar_amd.clutter_removal import LS_Filter, LS_Filter_Multiple, LS_Filter_Toeplitz, NLMS_filter
@@ -14,6 +14,8 @@ import threading
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 90.0
 nthreads = int(sys.argv[3]) if len(sys.argv) > 3 else 1        # dask-style concurrent callers
+logpath = sys.argv[4] if len(sys.argv) > 4 else None           # markdown record of the run (committed under profiles/)
+counts = {}
 rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-30))
 worst, fails, ncase = {}, [], 0
 lock = threading.Lock()
@@ -22,14 +24,46 @@ def note(kind, err, tol, desc):
     global ncase
     with lock:
         ncase += 1
+        counts[kind] = counts.get(kind, 0) + 1
         worst[kind] = max(worst.get(kind, 0.0), err)
         if not (err < tol):
             fails.append((kind, err, desc))
 def worker(wseed):
   rng = np.random.default_rng(wseed)
   while time.time() - t0 < budget:
-      k = rng.integers(0, 15)
-      if k == 0:      # CAF
+      k = rng.integers(0, 20)
+      if k == 15:     # wide range spans: AUTO takes the 4096-point team kernel (tails, several lag blocks, wrap)
+          F = int(rng.choice([2, 4, 16, 33])); N = int(rng.integers(8192, 300000)); R = int(rng.integers(600, min(5000, N // 2 - 1)))
+          ref, srv = scene.make_scene(N, 1e5, 300, int(rng.integers(1 << 30)))
+          w = None if rng.random() < 0.5 else np.kaiser(N, 4.0)
+          note("caf_wide", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("cafwide", N, R, F, w is not None))
+      elif k == 16:   # long LS filters on the 4096-point team kernels (770 .. 3073 taps), linear and circular
+          L = int(rng.choice([760, 790, 1024, 1500, 2047 - 10])); N = int(rng.integers(3 * L, 60000))
+          ref, srv = scene.make_scene(N, 1e6, 100, int(rng.integers(1 << 30)))
+          if rng.random() < 0.7:
+              bins = [0.0, 2.0, -1.0][:int(rng.integers(1, 4))]
+              note("ls_team", rel(LS_Filter_Multiple(ref, srv, L, 1e6, bins), O.LS_Filter_Multiple(ref, srv, L, 1e6, bins)), 1e-4, ("lsteam", N, L, bins))
+          else:
+              n2 = min(N, 12000)
+              note("ls_team_direct", rel(LS_Filter(ref[:n2], srv[:n2], L), O.LS_Filter(ref[:n2], srv[:n2], L)), 1e-4, ("lsteamdirect", n2, L))
+      elif k == 17:   # Doppler bins far from zero (beyond the Taylor range of the wrapped-sample phase), short and long blocks
+          N = int(rng.integers(3000, 120000)); L = int(rng.integers(2, 100)); fs = float(rng.choice([1e4, 2.6e5]))
+          bins = [0.0] + [float(b) for b in rng.uniform(-0.006 * fs, 0.006 * fs, int(rng.integers(1, 4)))]
+          ref, srv = scene.make_scene(N, fs, max(L, 50), int(rng.integers(1 << 30)))
+          note("ls_far_bins", rel(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)), 1e-4, ("lsfar", N, L, fs, bins))
+      elif k == 18:   # NLMS with a level step of 30-60 dB in the reference (u^H u must follow exactly)
+          N = int(rng.integers(1500, 8000)); L = int(rng.integers(4, 400)); mu = 0.05
+          ref, srv = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
+          g = np.ones(N, np.float32); a0 = int(rng.integers(N // 4, N // 2)); g[a0:a0 + int(rng.integers(50, N // 3))] = 10 ** (-float(rng.uniform(30, 60)) / 20)
+          r2, s2 = (ref * g).astype(np.complex64), (srv * g + 0.001 * srv).astype(np.complex64)
+          if N > L + 12:
+              note("nlms_step", rel(NLMS_filter(r2, s2, L, mu), c_oracle.nlms(r2, s2, L, mu)[0]), 1e-4, ("nlmsstep", N, L, a0))
+      elif k == 19:   # multi-bin LS on blocks long enough for the shared-inverse (Gohberg-Semencul) chain, config-2-like taps
+          N = int(rng.integers(20000, 400000)); L = int(rng.choice([16, 100, 256, 400])); fs = float(rng.choice([2.6e5, 2.4e6]))
+          bins = [0.0, 1.0, -1.0, 2.0, -2.0][:int(rng.integers(2, 6))]
+          ref, srv = scene.make_scene(N, fs, min(L, 200), int(rng.integers(1 << 30)))
+          note("ls_chain", rel(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)), 1e-4, ("lschain", N, L, fs, bins))
+      elif k == 0:      # CAF
           F = int(rng.choice([2, 8, 16, 51, 64, 128]))
           N = int(rng.integers(max(2 * F, 600), 40000))
           R = int(rng.integers(1, min(300, N // 3)))
@@ -142,4 +176,13 @@ threads = [threading.Thread(target=guarded, args=(seed * 1000 + i,)) for i in ra
 [t.join() for t in threads]
 print(f"{ncase} random cases in {time.time() - t0:.0f} s; worst relative error per kind:", {k: f"{v:.1e}" for k, v in worst.items()})
 print("FAILURES:", fails if fails else "none")
+if logpath:
+    with open(logpath, "w") as fh:
+        fh.write(f"# tests/fuzz_parity.py -- randomised drop-in vs oracle run on the MI355X box\n\n"
+                 f"seed {seed}, {budget:.0f} s budget, {nthreads} caller thread(s): **{ncase} cases, {len(fails)} failures**.\n"
+                 "Error = max|got - want| / max|want| per case (integer kinds: 0 or 1); the bar is 1e-4 for the LS / NLMS kinds,\n"
+                 "2e-5 for the CAF / helper kinds, 2e-6 for the block-phase shift.\n\n| kind | cases | worst error |\n|---|---|---|\n")
+        for k in sorted(worst):
+            fh.write(f"| {k} | {counts[k]} | {worst[k]:.2e} |\n")
+        fh.write("\nFailures: " + (repr(fails) if fails else "none") + "\n")
 sys.exit(1 if fails else 0)
