@@ -56,7 +56,7 @@ WORKLOADS = {
     "cfg5": (2.0e7, 1 << 23, 2048, 2048, None, 8),
 }
 N_ILLUMINATORS = {"cfg5": 4}
-SUB_BATCH = 256                # frames per CAF launch / per gather; LS launches take half of it
+SUB_BATCH = 256                # frames per CAF launch, per LS launch and per gather
 
 
 def synth_segment(torch, nchunks, C, fs, R, seed, device, t0=0.0):
@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--sub-batch", type=int, default=SUB_BATCH, help="frames per CAF launch and per gather")
     ap.add_argument("--caf-method", type=int, default=0, help="0 auto, 1 direct, 2 fft")
     ap.add_argument("--ls-method", type=int, default=0, help="0 auto, 1 time-domain, 2 FFT, 3 FFT + spectrum cache")
-    ap.add_argument("--nsub", type=int, default=2, help="LS sub-batches per CAF sub-batch when stages are pipelined")
+    ap.add_argument("--nsub", type=int, default=1, help="LS sub-batches per CAF sub-batch when stages are pipelined")
     ap.add_argument("--ls-streams", type=int, default=2, help="LS chains in flight (alternate sub-batches on separate streams)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run LS and CAF back to back on one stream instead of pipelining sub-batches on two")

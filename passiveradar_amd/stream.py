@@ -224,7 +224,7 @@ class HipBackend:
     def __init__(self, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
                  doppler_bins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), clutter="ls",
                  batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, overlap=True,
-                 ls_method=0, nsub=2, ls_streams=2):
+                 ls_method=0, nsub=1, ls_streams=2):
         import torch
         from . import engine
         from .range_doppler_processing import _named_window
@@ -239,7 +239,9 @@ class HipBackend:
         self.batch = int(batch)
         self.nlms_mu = float(nlms_mu)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        # pipelining doubles the latency-bound solve launches; it only pays once they are amortised
+        # LS launches of batch/nsub chunks.  Measured on MI355X (config 2, two LS chains in flight): 256-chunk launches
+        # (nsub = 1) 20.45 k frames/s, 128-chunk launches (nsub = 2) 19.56 k -- the latency-bound Durbin / solve kernels
+        # are per launch, so fewer, fuller launches win now that the second chain provides the overlap
         self.overlap = bool(overlap) and clutter == "ls" and self.batch >= 128
         # chunks per LS launch; NLMS is one wavefront per chunk, so splitting a batch would only idle SIMDs
         self.sub = -(-self.batch // max(int(nsub), 1)) if (self.overlap and clutter == "ls") else self.batch
