@@ -330,7 +330,9 @@ class HipBackend:
         if self.clutter is None:
             return srv_pad
         out = self._clean_target(srv_pad)
-        step = self.sub if self.clutter == "ls" else self.batch
+        # NLMS is one wavefront per hop chunk and needs no plan workspace: every local chunk goes into ONE launch
+        # (a 256-stream launch would leave three SIMDs in four idle); LS launches are bounded by the plan's workspace
+        step = self.sub if self.clutter == "ls" else max(nlocal, 1)
         with self.torch.cuda.device(self.device):
             for c0 in range(0, nlocal, step):
                 self._clean_range(ref_pad, srv_pad, out, c0, min(step, nlocal - c0), self._stream())

@@ -214,11 +214,12 @@ def test_plan_cache_evicts_with_close():
     assert closed == [0, 1]
 
 
-def test_committed_bench_line_follows_the_contract():
-    """profiles/r01_bench_default.json is bench.py's own output on the GPU box; the driver's contract fields must be there"""
+@pytest.mark.parametrize("tag", ["r01", "r02"])
+def test_committed_bench_line_follows_the_contract(tag):
+    """profiles/rNN_bench_default.json is bench.py's own output on the GPU box; the driver's contract fields must be there"""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_default.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{tag}_bench_default.json")
     d = json.load(open(path))
     base = json.load(open(os.path.join(os.path.dirname(path), "..", "BASELINE.json")))
     assert d["metric"].replace("x", "×") == base["metric"] or d["metric"] == base["metric"].replace("×", "x")
@@ -232,4 +233,10 @@ def test_committed_bench_line_follows_the_contract():
     assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
-    assert abs(d["value"] - 256 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) / d["value"] < 1e-6
+    frames = d["config"]["frames_per_gpu_per_step"]
+    assert frames == (256 if tag == "r01" else 5120)
+    assert abs(d["value"] - frames * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) / d["value"] < 1e-6
+    if tag != "r01":
+        assert d["timed_seconds"] >= 5.0                                       # long enough for the driver's sampler
+        assert c["cores"] == c["workers"] >= 1 and c["one_core_value"] > 0     # all-cores figure is measured, not scaled
+        assert r["traffic"] is None or "profiles/" in r["traffic_source"]
