@@ -3,6 +3,7 @@
  * Prints the peak cell and a checksum of one cross-ambiguity surface of a synthetic echo (delay 7 samples,
  * Doppler +5 cycles per CPI), which tests/test_gpu_parity.py compares with the Python drop-in. */
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include "prcore.h"
@@ -60,6 +61,33 @@ int main(void) {
             if (p > best) { best = p; br = r; bc = c; }
         }
     printf("peak row %d col %d power %.6e checksum %.6e\n", br, bc, best, sum);
+    /* The one collective of the path from C: gather of the per-rank map blocks to rank 0 (here a world of one; with
+     * several processes rank 0 ships `id` to the others, every rank calls prc_comm_create, and frames_per_rank
+     * lists every rank's block).  Skipped when RCCL is not installed (PRC_EUNSUPPORTED). */
+    {
+        unsigned char id[PRC_COMM_ID_BYTES];
+        int rc = prc_comm_unique_id(id);
+        if (rc == PRC_OK) {
+            prc_comm* comm = NULL;
+            void* dall = NULL;
+            const int64_t frames_per_rank[1] = {1};
+            CHK(prc_comm_create(&comm, id, 0, 1));
+            CHK(prc_malloc(&dall, sizeof(float) * 2 * F * (R + 1)));
+            CHK(prc_gather_frames(comm, dout, frames_per_rank, (int64_t)F * (R + 1), dall, 0, NULL));
+            CHK(prc_memcpy_d2h(ref, dall, sizeof(float) * 2 * F * (R + 1), NULL));   /* ref is free to reuse (2n floats) */
+            CHK(prc_stream_sync(NULL));
+            double diff = 0.0;
+            for (int i = 0; i < 2 * F * (R + 1); ++i) diff += fabs((double)ref[i] - (double)out[i]);
+            printf("gathered 1 frame through prc_gather_frames, difference %.1e\n", diff);
+            CHK(prc_comm_destroy(comm));
+            prc_free(dall);
+        } else if (rc == PRC_EUNSUPPORTED) {
+            printf("gather skipped: %s\n", prc_last_error());
+        } else {
+            fprintf(stderr, "prc_comm_unique_id -> %d: %s\n", rc, prc_last_error());
+            return 1;
+        }
+    }
     CHK(prc_caf_plan_destroy(plan));
     prc_free(dref); prc_free(dsrv); prc_free(dout);
     free(ref); free(srv); free(out);

@@ -1,6 +1,8 @@
 """The block pipeline of main.py:169-194 on the GPU (batched LS chunks + overlapped CAF frames)
 against the golden built from the reference's own functions, plus size-independent properties at
 BASELINE sizes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -277,3 +279,24 @@ def test_four_illuminator_step_equals_four_single_cafs():
     from oracle import np_oracle as O
     exp = O.fast_xambg(rp[C:C + n], sp[C:C + n], R, F, n, w)[:, :, 0]
     assert rel_err(got[1], exp) < 1e-4
+
+
+@pytest.mark.parametrize("args,frames", [(["--workload", "cfg4", "--frames", "21"], 21),
+                                          (["--workload", "cfg5", "--frames", "1"], 1),
+                                          (["--frames", "300"], 300)])
+def test_bench_workload_modes_run(args, frames):
+    """bench.py's workload modes at toy sizes (one GPU): the 600 s-stream mode on a 21-frame stream, the
+    four-illuminator mode, the default with a ragged last sub-batch -- one JSON line each with the contract's fields"""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--no-cpu", "--steps", "2", "--warmup", "1"] + args,
+                       capture_output=True, text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "frames/s"
+    assert d["config"]["frames_per_step_total"] == frames
+    assert d["scaling"] == ("strong" if "cfg4" in args else "weak")
+    assert d["roofline"]["bound"] in ("hbm", "valu") and 0 < d["roofline"]["frac"] < 1.5
+    assert abs(d["value"] - frames * d["steps"] / d["timed_seconds"]) / d["value"] < 1e-6
