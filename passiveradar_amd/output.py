@@ -9,8 +9,8 @@ chunk per frame, so writing is a plain dump of each frame.  Chunks are stored un
 zarr's defaults when *reading*.  zarr itself is not installed in this image, so the store is checked against
 the zarr v2 storage specification instead: ``validate_zarr_v2_metadata`` (required ``.zarray`` fields and their
 types) and ``read_zarr_v2``, a reader written from the specification (chunk grid, chunk file names, in-chunk
-order, edge chunks, fill value) that does not share code with the writer.  HDF5 output (main.py:208-214) is
-NOT built: h5py is unavailable and an HDF5 container could not be verified against a real reader here.
+order, edge chunks, fill value) that does not share code with the writer.  HDF5 output (main.py:208-214): h5py is
+not installed either, but the HDF5 C library is, so the file is written by libhdf5 itself through ctypes (see below).
 """
 from __future__ import annotations
 
@@ -20,7 +20,148 @@ import os
 import numpy as np
 
 __all__ = ["save_range_doppler", "save_range_doppler_zarr", "load_range_doppler_zarr", "save_metadata",
-           "validate_zarr_v2_metadata", "read_zarr_v2"]
+           "validate_zarr_v2_metadata", "read_zarr_v2", "save_range_doppler_hdf5", "load_range_doppler_hdf5",
+           "hdf5_available"]
+
+
+# ---- HDF5 (main.py:208-214) through the HDF5 C library itself ---------------------------------------------------
+# h5py is not installed here, but libhdf5 is (conda's copy in this image; any system copy elsewhere): the file is
+# written by the real library through ctypes -- dataset '/xambg', shape (F, R+1, nframes), complex64 stored the way
+# h5py stores NumPy complex numbers (compound {'r': float32, 'i': float32}), contiguous layout -- so that
+# range_doppler_plot.py:43-47 (`np.abs(f['/xambg'])`) reads it unchanged.
+_H5 = {"lib": None, "tried": False}
+
+
+def _hdf5_lib():
+    import ctypes as C
+    import ctypes.util
+    import glob
+    if _H5["tried"]:
+        return _H5["lib"]
+    _H5["tried"] = True
+    cands = [os.environ.get("PRC_HDF5_LIB"), ctypes.util.find_library("hdf5")]
+    for pat in ("/opt/conda/lib/libhdf5.so*", "/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so*",
+                "/usr/lib/x86_64-linux-gnu/libhdf5*.so*", "/usr/lib64/libhdf5.so*", "/usr/local/lib/libhdf5.so*"):
+        cands += sorted(glob.glob(pat))
+    for c in cands:
+        if not c:
+            continue
+        try:
+            h = C.CDLL(c)
+            if h.H5open() < 0:
+                continue
+        except (OSError, AttributeError):
+            continue
+        hid, hsz, pp = C.c_int64, C.c_uint64, C.POINTER(C.c_uint64)
+        sig = {"H5Fcreate": (hid, [C.c_char_p, C.c_uint, hid, hid]), "H5Fopen": (hid, [C.c_char_p, C.c_uint, hid]),
+               "H5Fclose": (C.c_int, [hid]), "H5Screate_simple": (hid, [C.c_int, pp, pp]), "H5Sclose": (C.c_int, [hid]),
+               "H5Sselect_hyperslab": (C.c_int, [hid, C.c_int, pp, pp, pp, pp]),
+               "H5Sget_simple_extent_ndims": (C.c_int, [hid]), "H5Sget_simple_extent_dims": (C.c_int, [hid, pp, pp]),
+               "H5Tcreate": (hid, [C.c_int, C.c_size_t]), "H5Tinsert": (C.c_int, [hid, C.c_char_p, C.c_size_t, hid]),
+               "H5Tclose": (C.c_int, [hid]), "H5Tget_class": (C.c_int, [hid]), "H5Tget_nmembers": (C.c_int, [hid]),
+               "H5Tget_member_name": (C.c_void_p, [hid, C.c_uint]), "H5Tget_size": (C.c_size_t, [hid]),
+               "H5free_memory": (C.c_int, [C.c_void_p]),
+               "H5Dcreate2": (hid, [hid, C.c_char_p, hid, hid, hid, hid, hid]), "H5Dopen2": (hid, [hid, C.c_char_p, hid]),
+               "H5Dget_space": (hid, [hid]), "H5Dget_type": (hid, [hid]), "H5Dclose": (C.c_int, [hid]),
+               "H5Dwrite": (C.c_int, [hid, hid, hid, hid, hid, C.c_void_p]),
+               "H5Dread": (C.c_int, [hid, hid, hid, hid, hid, C.c_void_p])}
+        try:
+            for name, (res, args) in sig.items():
+                fn = getattr(h, name)
+                fn.restype, fn.argtypes = res, args
+            h._f32le = C.c_int64.in_dll(h, "H5T_IEEE_F32LE_g").value
+        except (AttributeError, ValueError):
+            continue
+        _H5["lib"] = h
+        break
+    return _H5["lib"]
+
+
+def hdf5_available():
+    return _hdf5_lib() is not None
+
+
+def _h5_complex64(h):
+    t = h.H5Tcreate(6, 8)                                   # H5T_COMPOUND, 8 bytes
+    if t < 0 or h.H5Tinsert(t, b"r", 0, h._f32le) < 0 or h.H5Tinsert(t, b"i", 4, h._f32le) < 0:
+        raise OSError("HDF5: could not build the complex64 compound type")
+    return t
+
+
+def save_range_doppler_hdf5(path, frames, dataset="/xambg"):
+    """frames: [nframes][F][R+1] complex64 -> HDF5 file at ``path`` holding dataset '/xambg' of shape
+    (F, R+1, nframes) (main.py:208-214).  Frame i is written into the hyperslab [:, :, i]; nothing is transposed in
+    host memory."""
+    import ctypes as C
+    h = _hdf5_lib()
+    if h is None:
+        raise NotImplementedError("HDF5 output needs the HDF5 C library (libhdf5), which was not found; set "
+                                  "PRC_HDF5_LIB or use range_doppler_map_ftype: 'zarr'")
+    if hasattr(frames, "cpu"):
+        frames = frames.cpu().numpy()
+    frames = np.ascontiguousarray(frames, dtype=np.complex64)
+    nframes, F, cols = frames.shape
+    A3 = C.c_uint64 * 3
+    A2 = C.c_uint64 * 2
+    f = h.H5Fcreate(os.fsencode(path), 2, 0, 0)             # H5F_ACC_TRUNC
+    if f < 0:
+        raise OSError(f"HDF5: cannot create {path}")
+    t = fs = ms = d = -1
+    try:
+        t = _h5_complex64(h)
+        fs = h.H5Screate_simple(3, A3(F, cols, nframes), None)
+        ms = h.H5Screate_simple(2, A2(F, cols), None)
+        d = h.H5Dcreate2(f, dataset.encode(), t, fs, 0, 0, 0)
+        if min(fs, ms, d) < 0:
+            raise OSError("HDF5: dataset creation failed")
+        for i in range(nframes):
+            if h.H5Sselect_hyperslab(fs, 0, A3(0, 0, i), None, A3(F, cols, 1), None) < 0 or \
+                    h.H5Dwrite(d, t, ms, fs, 0, frames[i].ctypes.data) < 0:
+                raise OSError(f"HDF5: writing frame {i} failed")
+    finally:
+        for closer, hid in ((h.H5Dclose, d), (h.H5Sclose, ms), (h.H5Sclose, fs), (h.H5Tclose, t)):
+            if hid >= 0:
+                closer(hid)
+        h.H5Fclose(f)
+    return path
+
+
+def load_range_doppler_hdf5(path, dataset="/xambg"):
+    """Read '/xambg' back as the (F, R+1, nframes) complex64 array; checks that it is stored as h5py stores complex
+    numbers (compound of two float32 members named 'r' and 'i')."""
+    import ctypes as C
+    h = _hdf5_lib()
+    if h is None:
+        raise NotImplementedError("the HDF5 C library (libhdf5) was not found")
+    f = h.H5Fopen(os.fsencode(path), 0, 0)                  # H5F_ACC_RDONLY
+    if f < 0:
+        raise OSError(f"HDF5: cannot open {path}")
+    d = sp = ft = mt = -1
+    try:
+        d = h.H5Dopen2(f, dataset.encode(), 0)
+        if d < 0:
+            raise KeyError(dataset)
+        sp, ft = h.H5Dget_space(d), h.H5Dget_type(d)
+        nd = h.H5Sget_simple_extent_ndims(sp)
+        dims = (C.c_uint64 * max(nd, 1))()
+        h.H5Sget_simple_extent_dims(sp, dims, None)
+        names = []
+        for m in range(max(h.H5Tget_nmembers(ft), 0)):
+            p = h.H5Tget_member_name(ft, m)
+            names.append(C.string_at(p).decode())
+            h.H5free_memory(p)
+        if h.H5Tget_class(ft) != 6 or names != ["r", "i"] or h.H5Tget_size(ft) != 8:
+            raise ValueError(f"{dataset} is not a complex64 dataset in h5py's convention (members {names})")
+        out = np.empty(tuple(int(v) for v in dims), dtype=np.complex64)
+        mt = _h5_complex64(h)
+        if h.H5Dread(d, mt, 0, 0, 0, out.ctypes.data) < 0:    # H5S_ALL
+            raise OSError("HDF5: read failed")
+        return out
+    finally:
+        for closer, hid in ((h.H5Tclose, mt), (h.H5Tclose, ft), (h.H5Sclose, sp), (h.H5Dclose, d)):
+            if hid >= 0:
+                closer(hid)
+        h.H5Fclose(f)
 
 
 def validate_zarr_v2_metadata(meta):
@@ -93,15 +234,14 @@ def read_zarr_v2(path):
 
 def save_range_doppler(config, frames):
     """main.py:208-227: write the maps in the format ``config['range_doppler_map_ftype']`` names, to
-    ``config['range_doppler_map_fname']`` (dict of passiveradar_amd.config.getConfiguration).  'zarr' is built;
-    'hdf5' is not (h5py is not available to this build and an HDF5 container written without it could not be
-    verified against a real reader): NotImplementedError.  Anything else: the reference's ValueError."""
+    ``config['range_doppler_map_fname']`` (dict of passiveradar_amd.config.getConfiguration).  'zarr': directory
+    store written here; 'hdf5': dataset '/xambg' written through the HDF5 C library (NotImplementedError if libhdf5
+    cannot be found).  Anything else: the reference's ValueError."""
     ftype = config["range_doppler_map_ftype"]
     if ftype == "zarr":
         return save_range_doppler_zarr(config["range_doppler_map_fname"], frames)
     if ftype == "hdf5":
-        raise NotImplementedError("HDF5 output (main.py:208-214, dataset '/xambg') is not built: h5py is not "
-                                  "available here; use range_doppler_map_ftype: 'zarr'")
+        return save_range_doppler_hdf5(config["range_doppler_map_fname"], frames)
     raise ValueError("Unsupported output file type. Enter 'hdf5' or 'zarr'")
 
 
