@@ -49,7 +49,9 @@ WORKLOADS = {
     "cfg2": (2.4e6, 2400000, 256, 512, "ls", 5120),
     "cfg2p2": (2.4e6, 2097152, 256, 512, "ls", 2048),
     "cfg1": (262184.87, 262144, 256, 256, "ls", 4096),
-    "cfg3": (1.0e7, 5000000, 1024, 1024, "nlms", 1024),
+    # 3072 hop chunks per step: NLMS is one wavefront per chunk, and three wavefronts per SIMD (3 x 1024 SIMDs) issue
+    # 1.36x the steps per second of one (61 GB per stream resident)
+    "cfg3": (1.0e7, 5000000, 1024, 1024, "nlms", 3072),
     # config 4: 600 s of cfg-2 IQ, hop 0.5 s -> 1200 chunks, trimmed by one (main.py:116-120) -> 1199 frames
     "cfg4": (2.4e6, 2400000, 256, 512, "ls", 1199),
     # config 5: 20 MS/s, 2048 x 2048, four illuminators against one surveillance channel, CAF only
