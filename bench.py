@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--caf-method", type=int, default=0, help="0 auto, 1 direct, 2 fft")
     ap.add_argument("--ls-method", type=int, default=0, help="0 auto, 1 time-domain, 2 FFT, 3 FFT + spectrum cache")
     ap.add_argument("--nsub", type=int, default=1, help="LS sub-batches per CAF sub-batch when stages are pipelined")
-    ap.add_argument("--ls-streams", type=int, default=2, help="LS chains in flight (alternate sub-batches on separate streams)")
+    ap.add_argument("--ls-streams", type=int, default=3, help="LS chains in flight (alternate sub-batches on separate streams)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run LS and CAF back to back on one stream instead of pipelining sub-batches on two")
     ap.add_argument("--gather", default="auto", choices=["auto", "prc", "torch", "none"],
