@@ -296,8 +296,13 @@ def main():
         if pending[k] is not None:
             pending[k][1].wait()
         s_comm.wait_stream(torch.cuda.current_stream())
+        sh, out = gshard, recv[k]
+        if not strong and block.shape[0] != gsize:   # ragged last sub-batch: every rank sends the same shorter block
+            m = int(block.shape[0])
+            sh = prstream.Shard(rank, world, m * world, rank * m, (rank + 1) * m, 0, m)
+            out = recv[k][:m * world] if rank == 0 else None
         with torch.cuda.stream(s_comm):
-            res, work = prstream.gather_frames(block, gshard, async_op=True, out=recv[k], comm=comm, stream=s_comm)
+            res, work = prstream.gather_frames(block, sh, async_op=True, out=out, comm=comm, stream=s_comm)
         block.record_stream(s_comm)
         pending[k] = (block, work)
 
