@@ -46,7 +46,7 @@ MIN_TIMED_SECONDS = 5.0        # auto-sized runs time at least this long
 
 WORKLOADS = {
     # name: (Fs, N, R, F, clutter, default frames per GPU per step)
-    "cfg2": (2.4e6, 2400000, 256, 512, "ls", 5120),
+    "cfg2": (2.4e6, 2400000, 256, 512, "ls", 5632),
     "cfg2p2": (2.4e6, 2097152, 256, 512, "ls", 2048),
     "cfg1": (262184.87, 262144, 256, 256, "ls", 4096),
     # 3072 hop chunks per step: NLMS is one wavefront per chunk, and three wavefronts per SIMD (3 x 1024 SIMDs) issue
@@ -84,7 +84,7 @@ def synth_segment(torch, nchunks, C, fs, R, seed, device, t0=0.0):
 
 def synth_padded(torch, nchunks, C, fs, R, seed, device, seg_chunks=128, add_to=None):
     """[C/2 zeros | nchunks chunks | C/2 zeros] reference and surveillance streams, generated segment by
-    segment (a 5120-chunk stream is 49 GB per channel; the generator's temporaries are kept to one
+    segment (a 5632-chunk stream is 54 GB per channel; the generator's temporaries are kept to one
     segment).  add_to: an existing padded surveillance stream to accumulate into (further illuminators)."""
     ref_pad = torch.zeros(nchunks * C + C, dtype=torch.complex64, device=device)
     srv_pad = add_to if add_to is not None else torch.zeros(nchunks * C + C, dtype=torch.complex64, device=device)

@@ -253,7 +253,7 @@ def test_committed_bench_line_follows_the_contract(tag):
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     frames = d["config"]["frames_per_gpu_per_step"]
-    assert frames == (256 if tag == "r01" else 5120)
+    assert frames == (256 if tag == "r01" else 5632)
     assert abs(d["value"] - frames * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) / d["value"] < 1e-6
     if tag != "r01":
         assert d["timed_seconds"] >= 5.0                                       # long enough for the driver's sampler
