@@ -301,6 +301,58 @@ def big_cases():
              peak=mag.max())
 
 
+def _surface_digest(out2d):
+    """What the full-size digests keep of a surface: every 8th cell, the 64 strongest cells, row and column sums."""
+    mag = np.abs(out2d)
+    top = np.argsort(mag.ravel())[-64:]
+    return dict(sub=out2d[::8, ::8], top_idx=top, top_val=out2d.ravel()[top], col_sums=out2d.sum(axis=0),
+                row_sums=out2d.sum(axis=1), peak=mag.max())
+
+
+def _cfg5_one(i):
+    n, R, F, fs = 1 << 23, 2048, 2048, 2.0e7
+    seeds = [scene.scene_seed(5, c) for c in range(4)]
+    refs, srv = scene.make_multi_scene(n, fs, R, seeds)
+    w = signal.get_window(("kaiser", 5.0), n)
+    t0 = time.time()
+    with no_root_finding():
+        out = ref_rd.fast_xambg(refs[i], srv, R, F, n, w)[:, :, 0]
+    print(f"  cfg5 illuminator {i}: {time.time() - t0:.1f}s", flush=True)
+    return _surface_digest(out)
+
+
+def caf_cfg5_digest_case():
+    """BASELINE config 5 at full size through the reference's own fast_xambg: 20 MS/s, N = 2^23, 2048 x 2048, four
+    independent white illuminators against one surveillance channel that carries every illuminator's scene
+    (range_doppler_processing.py:12-90 once per pair, as the reference would be called).  One digest per surface."""
+    print("config-5 CAF digests (4 surfaces of 2049 x 2048; four worker processes, several minutes each)")
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(4) as pool:
+        digs = pool.map(_cfg5_one, range(4))
+    arrays = {}
+    for i, d in enumerate(digs):
+        for k, v in d.items():
+            arrays[f"ill{i}_{k}"] = v
+    save("caf_cfg5_digest", seeds=np.array([scene.scene_seed(5, c) for c in range(4)]), N=1 << 23, R=2048, F=2048,
+         fs=2.0e7, **arrays)
+
+
+def nlms_cfg3_digest_case():
+    """BASELINE config 3's clutter stage at full hop length through the reference's own NLMS_filter
+    (clutter_removal.py:189-249): 2.5 M samples, filterLen 1024 (T = 1034), mu = 0.02, cold start.  Kept: every
+    997th output sample, the first and last 4096, and the final taps."""
+    print("config-3 NLMS hop (2.5 M sequential steps of the reference's Python loop, about a minute or two)")
+    n, L, fs = 2500000, 1024, 1.0e7
+    a, s = scene.make_scene(n, fs, L, scene.scene_seed(3))
+    t0 = time.time()
+    out, taps = ref_cr.NLMS_filter(a, s, L, 0.02, 10, None, True)
+    print(f"  {time.time() - t0:.1f}s")
+    save("nlms_cfg3_digest", seed=scene.scene_seed(3), N=n, L=L, fs=fs, mu=0.02, peek=10,
+         sub=out[::997].astype(np.complex64), head=out[:4096].astype(np.complex64),
+         tail=out[-4096:].astype(np.complex64), taps=np.asarray(taps).astype(np.complex64),
+         peak=np.abs(out).max(), energy=np.float64(np.vdot(out, out).real))
+
+
 def ls_cfg1_case():
     """BASELINE config 1 (the reference's own CPU-runnable case): one 131 072-sample hop chunk of the 262 184.87 Hz
     IF stream through LS_Filter_Multiple with 256 range cells (T = 266) and the five Doppler bins of main.py:169-176."""
@@ -443,3 +495,5 @@ if __name__ == "__main__":
         pipeline_cfg1_case()
         pipeline_cfg2_case()
         pipeline_cfg2_c128_case()
+        nlms_cfg3_digest_case()
+        caf_cfg5_digest_case()

@@ -67,6 +67,17 @@ def make_scene(n, sample_rate, rangeBins, seed, targets=None, clutter=DEFAULT_CL
     return ref, acc.astype(np.complex64)
 
 
+def make_multi_scene(n, sample_rate, rangeBins, seeds, **kw):
+    """Several illuminators against ONE surveillance channel: independent white
+    reference channels, srv = sum of each channel's scene.  Returns ([ref_i], srv), complex64."""
+    refs, acc = [], np.zeros(n, dtype=np.complex128)
+    for sd in seeds:
+        r, s = make_scene(n, sample_rate, rangeBins, sd, **kw)
+        refs.append(r)
+        acc += s
+    return refs, acc.astype(np.complex64)
+
+
 def make_stream(nchunks, chunk, sample_rate, rangeBins, seed, **kw):
     """A contiguous IF stream of nchunks*chunk samples (one scene; delays wrap at the ends)."""
     return make_scene(nchunks * chunk, sample_rate, rangeBins, seed, **kw)

@@ -552,6 +552,22 @@ def test_nlms_full_cfg3_hop_vs_c_oracle():
     assert e_end < TOL                                        # no drift at the far end either
 
 
+def test_nlms_full_cfg3_hop_vs_reference_digest():
+    """the same hop against the REFERENCE's own NLMS_filter output (clutter_removal.py:189-249 run for 2.5 M steps
+    by oracle/gen_golden.py nlms_cfg3_digest_case): strided samples, both ends, final taps, output energy"""
+    from passiveradar_amd.clutter_removal import NLMS_filter
+    g = load_golden("nlms_cfg3_digest")
+    n, L = int(g["N"]), int(g["L"])
+    ref, srv = scene.make_scene(n, float(g["fs"]), L, int(g["seed"]))
+    out, taps = NLMS_filter(ref, srv, L, float(g["mu"]), int(g["peek"]), None, True)
+    peak = float(g["peak"])
+    assert np.abs(out[::997] - g["sub"]).max() / peak < TOL
+    assert np.abs(out[:4096] - g["head"]).max() / peak < TOL
+    assert np.abs(out[-4096:] - g["tail"]).max() / peak < TOL
+    assert rel_err(taps, g["taps"]) < TOL
+    assert abs(float(np.vdot(out, out).real) / float(g["energy"]) - 1) < TOL
+
+
 def test_nlms_reference_level_step():
     """the reference channel drops by 50 dB (and comes back) inside the tap window: u^H u must follow exactly,
     as the reference's per-step re-sum does (:213) -- a float32 sliding sum alone loses it to cancellation"""

@@ -274,3 +274,20 @@ def test_ls_at_the_config3_tap_count():
     # the reference solves and applies this one in complex64 (1034-term float32 dot products, no block edges: the
     # residual that normalises the error is only ~0.05 of the input): taps to 1e-6, output to 1e-3 of its own peak
     assert rel_err(taps, g["taps"]) < 5e-6 and rel_err(out, g["out"]) < 1e-3
+
+
+def test_nlms_cfg3_hop_c_twin_vs_reference_digest():
+    """config 3's NLMS stage at FULL hop length (2.5 M samples, T = 1034, mu = 0.02): the C twin of the oracle against
+    the digest the reference's own NLMS_filter produced (clutter_removal.py:189-249, oracle/gen_golden.py
+    nlms_cfg3_digest_case) -- pins the checker the GPU test leans on at the size it is used"""
+    from oracle import c_oracle
+    g = load_golden("nlms_cfg3_digest")
+    n, L = int(g["N"]), int(g["L"])
+    ref, srv = scene.make_scene(n, float(g["fs"]), L, int(g["seed"]))
+    out, taps = c_oracle.nlms(ref, srv, L, float(g["mu"]), int(g["peek"]))
+    peak = float(g["peak"])
+    assert np.abs(out[::997] - g["sub"]).max() / peak < 1e-4
+    assert np.abs(out[:4096] - g["head"]).max() / peak < 1e-4
+    assert np.abs(out[-4096:] - g["tail"]).max() / peak < 1e-4
+    assert rel_err(taps, g["taps"]) < 1e-4
+    assert abs(float(np.vdot(out, out).real) / float(g["energy"]) - 1) < 1e-4
