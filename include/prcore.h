@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRC_VERSION 200
+#define PRC_VERSION 300
 
 typedef enum prc_status {
     PRC_OK = 0,
@@ -67,9 +67,11 @@ typedef enum prc_caf_method {
 } prc_caf_method;
 
 typedef enum prc_doppler_method {
-    PRC_DOPPLER_AUTO = 0,
-    PRC_DOPPLER_ROCFFT = 1  /* batched 1-D rocFFT over the slow-time axis (any freq_bins) +
+    PRC_DOPPLER_AUTO = 0,   /* COLUMN when freq_bins is 256, 512, 1024, 2048 or 4096, else ROCFFT           */
+    PRC_DOPPLER_ROCFFT = 1, /* transpose + batched 1-D rocFFT over the slow-time axis (any freq_bins) +
                                one fftshift/transpose kernel (:89)                           */
+    PRC_DOPPLER_COLUMN = 2  /* one column-FFT kernel over the row-major slow-time buffer, fftshift folded
+                               into the store: the surface is read once and written once    */
 } prc_doppler_method;
 
 typedef struct prc_caf_desc {
@@ -100,6 +102,15 @@ int prc_caf_plan_info(const prc_caf_plan* plan, int32_t* method, int32_t* dopple
 int prc_caf_execute(prc_caf_plan* plan, const void* ref, const void* srv, int64_t frame_stride,
                     int64_t n_valid, const float* window, void* out, int32_t nframes,
                     void* stream);
+/* fast_xambg for nref (<= 8) reference channels against ONE surveillance channel in one call -- a multi-illuminator
+ * frame (range_doppler_processing.py:12-90 once per pair; :81-86 is the per-pair unit): outs_host[i] receives what
+ * prc_caf_execute(plan, refs_host[i], srv, ...) would write.  refs_host / outs_host are HOST arrays of nref DEVICE
+ * pointers.  nframes * nref surfaces must fit the plan's max_frames.  With the 4096-point method and segments of at
+ * most two pieces (wide range spans: BASELINE configs 3 and 5) the surveillance pieces are transformed once per
+ * segment for all illuminators; otherwise the illuminators take turns through the single-reference kernels. */
+int prc_caf_execute_multi(prc_caf_plan* plan, const void* const* refs_host, int32_t nref, const void* srv,
+                          int64_t frame_stride, int64_t n_valid, const float* window, void* const* outs_host,
+                          int32_t nframes, void* stream);
 /* Stages timed separately by bench.py (same arguments; `segment` writes the plan's internal
  * slow-time buffer, `doppler` turns it into out). */
 int prc_caf_execute_segments(prc_caf_plan* plan, const void* ref, const void* srv,

@@ -301,11 +301,11 @@ def big_cases():
              peak=mag.max())
 
 
-def _surface_digest(out2d):
-    """What the full-size digests keep of a surface: every 8th cell, the 64 strongest cells, row and column sums."""
+def _surface_digest(out2d, step=16):
+    """What the full-size digests keep of a surface: every step-th cell, the 64 strongest cells, row and column sums."""
     mag = np.abs(out2d)
     top = np.argsort(mag.ravel())[-64:]
-    return dict(sub=out2d[::8, ::8], top_idx=top, top_val=out2d.ravel()[top], col_sums=out2d.sum(axis=0),
+    return dict(sub=out2d[::step, ::step], top_idx=top, top_val=out2d.ravel()[top], col_sums=out2d.sum(axis=0),
                 row_sums=out2d.sum(axis=1), peak=mag.max())
 
 

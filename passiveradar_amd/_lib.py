@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("PRCORE_LIB", os.path.join(_HERE, "libprcore.so"))   #
 
 PRC_OK, PRC_EINVAL, PRC_ESHAPE, PRC_EHIP, PRC_EROCFFT, PRC_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 CAF_AUTO, CAF_DIRECT, CAF_FFT, CAF_FFT4096 = 0, 1, 2, 3
-DOPPLER_AUTO, DOPPLER_ROCFFT = 0, 1
+DOPPLER_AUTO, DOPPLER_ROCFFT, DOPPLER_COLUMN = 0, 1, 2
+CAF_MAX_REFS = 8
 COMM_ID_BYTES = 128
 
 
@@ -73,6 +74,8 @@ _SIGNATURES = {
                                     C.POINTER(C.c_int64)]),
     "prc_caf_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "prc_caf_execute_multi": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64,
+                                        C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "prc_caf_execute_segments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                            C.c_void_p, C.c_int32, C.c_void_p]),
     "prc_caf_execute_doppler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -1,9 +1,15 @@
 // Cross-ambiguity plan: segment sums (caf_direct.hip / caf_fft.hip) + Doppler FFT + fftshift.
 //
 // Replaces fast_xambg, range_doppler_processing.py:12-90.  The Doppler stage (:89,
-// scipy.fftpack.fft(axis=0) then np.fft.fftshift) is either a rocFFT batched 1-D plan over
-// the contiguous slow-time axis followed by one shift+transpose kernel.
+// scipy.fftpack.fft(axis=0) then np.fft.fftshift) is ONE column-FFT kernel over the row-major slow-time
+// buffer for power-of-two freq_bins from 256 to 4096 (doppler_col.h), and for any other size a rocFFT batched
+// 1-D plan over the contiguous slow-time axis between a transpose and a shift+transpose kernel.
+//
+// Segment sums and Doppler transforms alternate over groups of surfaces sized to the Infinity Cache, so the
+// slow-time buffer is read back from the cache that took its writes rather than from HBM.
 #include "caf_internal.h"
+#include "doppler_col.h"
+#include <stdlib.h>
 #include <rocfft/rocfft.h>
 #include <vector>
 
@@ -20,8 +26,10 @@ struct prc_caf_plan {
     int ntaps;
     int half;
     float* d_taps = nullptr;         // device copy of the long decimation FIR (or null)
-    float2* d_y = nullptr;           // slow-time buffer, max_frames * F * (R+1)
-    float2* d_y2 = nullptr;          // [j][k]-ordered staging written by the FFT segment kernel
+    float2* d_y = nullptr;           // [k][j]-ordered slow-time buffer of the rocFFT path, max_frames * F * (R+1)
+    float2* d_y2 = nullptr;          // [j][k]-ordered slow-time buffer written row-wise by the segment kernels
+    float2* d_dop_tw = nullptr;      // W_F^m table of the column-FFT Doppler kernel
+    int group = 1;                   // surfaces per segment/Doppler round of prc_caf_execute
     size_t y_bytes = 0;
     rocfft_plan fft = nullptr;       // one batched plan for max_frames
     rocfft_execution_info info = nullptr;
@@ -76,6 +84,21 @@ static int build_rocfft(prc_caf_plan* p, int frames) {
     return PRC_OK;
 }
 
+// surfaces per segment/Doppler round: as many as keep the slow-time buffer inside the Infinity Cache next to
+// the inputs that stream through it (PRC_CAF_GROUP_MB overrides the budget; measured in DESIGN.md)
+static int pick_group(const prc_caf_desc* d) {
+    double mb = 96.0;
+    if (const char* e = getenv("PRC_CAF_GROUP_MB")) {
+        const double v = atof(e);
+        if (v > 0) mb = v;
+    }
+    const double surf = 8.0 * (double)d->freq_bins * (double)(d->range_bins + 1);
+    int g = (int)(mb * 1048576.0 / surf);
+    if (g < 1) g = 1;
+    if (g > d->max_frames) g = d->max_frames;
+    return g;
+}
+
 extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
     PRC_REQUIRE(plan && d, PRC_EINVAL, "prc_caf_plan_create: null argument");
     PRC_REQUIRE(d->n > 0 && d->range_bins >= 0 && d->freq_bins > 0 && d->max_frames > 0,
@@ -116,8 +139,16 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
         delete p;
         return PRC_EUNSUPPORTED;
     }
-    p->doppler = d->doppler == PRC_DOPPLER_AUTO ? PRC_DOPPLER_ROCFFT : d->doppler;
-    if (p->doppler != PRC_DOPPLER_ROCFFT) {
+    p->doppler = d->doppler;
+    if (p->doppler == PRC_DOPPLER_AUTO)
+        p->doppler = dop_supported(d->freq_bins) ? PRC_DOPPLER_COLUMN : PRC_DOPPLER_ROCFFT;
+    if (p->doppler == PRC_DOPPLER_COLUMN && !dop_supported(d->freq_bins)) {
+        prc_set_error("prc_caf_plan_create: the column-FFT Doppler kernel takes freq_bins 256, 512, 1024, 2048, 4096 "
+                      "(got %d)", d->freq_bins);
+        delete p;
+        return PRC_EUNSUPPORTED;
+    }
+    if (p->doppler != PRC_DOPPLER_ROCFFT && p->doppler != PRC_DOPPLER_COLUMN) {
         prc_set_error("prc_caf_plan_create: unknown Doppler method %d", d->doppler);
         delete p;
         return PRC_EINVAL;
@@ -125,16 +156,16 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
     int rc = PRC_OK;
     auto fail = [&](int code) { prc_caf_plan_destroy(p); return code; };
     p->y_bytes = sizeof(float2) * (size_t)d->max_frames * d->freq_bins * (d->range_bins + 1);
-    if (hipMalloc(&p->d_y, p->y_bytes) != hipSuccess) {
+    p->group = pick_group(d);
+    const bool rowwise = p->method == PRC_CAF_FFT || p->method == PRC_CAF_FFT4096 || p->doppler == PRC_DOPPLER_COLUMN;
+    if (p->doppler == PRC_DOPPLER_ROCFFT && hipMalloc(&p->d_y, p->y_bytes) != hipSuccess) {
         prc_set_error("prc_caf_plan_create: hipMalloc(%zu) failed: %s", p->y_bytes,
                       hipGetErrorString(hipGetLastError()));
         return fail(PRC_EHIP);
     }
-    if ((p->method == PRC_CAF_FFT || p->method == PRC_CAF_FFT4096) && p->doppler == PRC_DOPPLER_ROCFFT) {
-        if (hipMalloc(&p->d_y2, p->y_bytes) != hipSuccess) {
-            prc_set_error("prc_caf_plan_create: hipMalloc(%zu) failed", p->y_bytes);
-            return fail(PRC_EHIP);
-        }
+    if (rowwise && hipMalloc(&p->d_y2, p->y_bytes) != hipSuccess) {
+        prc_set_error("prc_caf_plan_create: hipMalloc(%zu) failed", p->y_bytes);
+        return fail(PRC_EHIP);
     }
     if (!boxcar) {
         if (hipMalloc(&p->d_taps, sizeof(float) * d->ntaps) != hipSuccess ||
@@ -146,6 +177,14 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
     if (p->doppler == PRC_DOPPLER_ROCFFT) {
         rc = build_rocfft(p, d->max_frames);
         if (rc != PRC_OK) return fail(rc);
+    } else {
+        std::vector<float2> tw((size_t)d->freq_bins);
+        dop_make_table(tw.data(), d->freq_bins);
+        if (hipMalloc(&p->d_dop_tw, sizeof(float2) * tw.size()) != hipSuccess ||
+            hipMemcpy(p->d_dop_tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            prc_set_error("prc_caf_plan_create: Doppler twiddle upload failed");
+            return fail(PRC_EHIP);
+        }
     }
     *plan = p;
     return PRC_OK;
@@ -159,6 +198,7 @@ extern "C" int prc_caf_plan_destroy(prc_caf_plan* p) {
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_y) (void)hipFree(p->d_y);
     if (p->d_y2) (void)hipFree(p->d_y2);
+    if (p->d_dop_tw) (void)hipFree(p->d_dop_tw);
     delete p;
     return PRC_OK;
 }
@@ -168,7 +208,8 @@ extern "C" int prc_caf_plan_info(const prc_caf_plan* p, int32_t* method, int32_t
     PRC_REQUIRE(p, PRC_EINVAL, "prc_caf_plan_info: null plan");
     if (method) *method = p->method;
     if (doppler) *doppler = p->doppler;
-    if (workspace_bytes) *workspace_bytes = (int64_t)(p->y_bytes * (p->d_y2 ? 2 : 1) + p->work_bytes);
+    if (workspace_bytes)
+        *workspace_bytes = (int64_t)(p->y_bytes * ((p->d_y ? 1 : 0) + (p->d_y2 ? 1 : 0)) + p->work_bytes);
     return PRC_OK;
 }
 
@@ -179,18 +220,22 @@ static int check_exec(prc_caf_plan* p, int nframes, const char* who) {
     return PRC_OK;
 }
 
+static int64_t surf_elems(const prc_caf_plan* p) {
+    return (int64_t)p->desc.freq_bins * (p->desc.range_bins + 1);
+}
+
+// segment sums of frames [f0, f0 + nf) of one reference channel into the plan's slow-time buffer, surfaces s0...
 static int run_segments(prc_caf_plan* p, const void* ref, const void* srv, int64_t frame_stride,
-                        int64_t n_valid, const float* window, int nframes, hipStream_t stream) {
+                        int64_t n_valid, const float* window, int f0, int nf, int s0, hipStream_t stream) {
     PRC_REQUIRE(ref && srv, PRC_EINVAL, "prc_caf_execute: null input");
     PRC_REQUIRE(n_valid >= 0 && n_valid <= p->desc.n, PRC_ESHAPE,
                 "prc_caf_execute: n_valid=%lld exceeds inputLen=%lld", (long long)n_valid,
                 (long long)p->desc.n);
     CafSegArgs a;
-    a.ref = (const float2*)ref;
-    a.srv = (const float2*)srv;
+    a.ref = (const float2*)ref + (int64_t)f0 * frame_stride;
+    a.srv = (const float2*)srv + (int64_t)f0 * frame_stride;
     a.window = window;
     a.taps = p->d_taps;
-    a.y = p->d_y;
     a.frame_stride = frame_stride;
     a.n = p->desc.n;
     a.n_valid = n_valid;
@@ -199,29 +244,37 @@ static int run_segments(prc_caf_plan* p, const void* ref, const void* srv, int64
     a.half = p->half;
     a.range_bins = p->desc.range_bins;
     a.freq_bins = p->desc.freq_bins;
-    a.y_layout = PRC_Y_KJ;
+    const int64_t off = (int64_t)s0 * surf_elems(p);
     if (p->method == PRC_CAF_FFT || p->method == PRC_CAF_FFT4096) {
-        // the FFT kernels write whole rows y[j][0..R] (coalesced); rocFFT wants j contiguous
-        a.y = p->d_y2;
+        // the FFT kernels write whole rows y[j][0..R] (coalesced)
+        a.y = p->d_y2 + off;
         a.y_layout = PRC_Y_JK;
-        int rc = p->method == PRC_CAF_FFT ? caf_launch_fft(a, nframes, stream) : caf_launch_fft_team(a, nframes, stream);
+        int rc = p->method == PRC_CAF_FFT ? caf_launch_fft(a, nf, stream) : caf_launch_fft_team(a, nf, stream);
         if (rc) return rc;
-        return caf_launch_transpose_jk_kj(p->d_y2, p->d_y, a.freq_bins, a.range_bins + 1, nframes, stream);
+        if (p->doppler == PRC_DOPPLER_ROCFFT)       // rocFFT wants j contiguous
+            return caf_launch_transpose_jk_kj(p->d_y2 + off, p->d_y + off, a.freq_bins, a.range_bins + 1, nf, stream);
+        return PRC_OK;
     }
-    return caf_launch_direct(a, nframes, stream);
+    a.y = (p->doppler == PRC_DOPPLER_COLUMN ? p->d_y2 : p->d_y) + off;
+    a.y_layout = p->doppler == PRC_DOPPLER_COLUMN ? PRC_Y_JK : PRC_Y_KJ;
+    return caf_launch_direct(a, nf, stream);
 }
 
-static int run_doppler(prc_caf_plan* p, void* out, int nframes, hipStream_t stream) {
+// Doppler transform + fftshift of surfaces [s0, s0 + ns) of the slow-time buffer into out (surface s0 first)
+static int run_doppler(prc_caf_plan* p, void* out, int s0, int ns, hipStream_t stream) {
     PRC_REQUIRE(out, PRC_EINVAL, "prc_caf_execute: null output");
     const int F = p->desc.freq_bins, cols = p->desc.range_bins + 1;
-    // rocFFT: the plan is batched for max_frames; transforming the unused tail is harmless
-    // (it lives in the plan's own buffer) and keeps one plan per shape.
+    if (p->doppler == PRC_DOPPLER_COLUMN)
+        return dop_launch(p->d_y2 + (int64_t)s0 * surf_elems(p), (float2*)out, p->d_dop_tw, F, cols, ns, stream);
+    // rocFFT: the plan is batched for max_frames and always transforms the whole buffer (one plan per shape); the
+    // surfaces outside [s0, s0 + ns) are transformed in place too, so this path takes whole batches only
+    PRC_REQUIRE(s0 == 0, PRC_EINVAL, "prc_caf_execute: the rocFFT Doppler path transforms whole batches");
     rocfft_status st = rocfft_execution_info_set_stream(p->info, stream);
     PRC_REQUIRE(st == rocfft_status_success, PRC_EROCFFT, "rocfft set stream failed (%d)", (int)st);
     void* bufs[1] = {p->d_y};
     st = rocfft_execute(p->fft, bufs, nullptr, p->info);
     PRC_REQUIRE(st == rocfft_status_success, PRC_EROCFFT, "rocfft_execute failed (%d)", (int)st);
-    dim3 grid((F + 31) / 32, (cols + 31) / 32, nframes);
+    dim3 grid((F + 31) / 32, (cols + 31) / 32, ns);
     hipLaunchKernelGGL(shift_transpose_kernel, grid, dim3(256), 0, stream, p->d_y, (float2*)out, F, cols);
     PRC_LAUNCH_CHECK();
     return PRC_OK;
@@ -233,14 +286,14 @@ extern "C" int prc_caf_execute_segments(prc_caf_plan* p, const void* ref, const 
     int rc = check_exec(p, nframes, "prc_caf_execute_segments");
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(p->mtx);
-    return run_segments(p, ref, srv, frame_stride, n_valid, window, nframes, (hipStream_t)stream);
+    return run_segments(p, ref, srv, frame_stride, n_valid, window, 0, nframes, 0, (hipStream_t)stream);
 }
 
 extern "C" int prc_caf_execute_doppler(prc_caf_plan* p, void* out, int32_t nframes, void* stream) {
     int rc = check_exec(p, nframes, "prc_caf_execute_doppler");
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(p->mtx);
-    return run_doppler(p, out, nframes, (hipStream_t)stream);
+    return run_doppler(p, out, 0, nframes, (hipStream_t)stream);
 }
 
 extern "C" int prc_caf_execute(prc_caf_plan* p, const void* ref, const void* srv, int64_t frame_stride,
@@ -248,8 +301,83 @@ extern "C" int prc_caf_execute(prc_caf_plan* p, const void* ref, const void* srv
                                void* stream) {
     int rc = check_exec(p, nframes, "prc_caf_execute");
     if (rc) return rc;
+    PRC_REQUIRE(out, PRC_EINVAL, "prc_caf_execute: null output");
     std::lock_guard<std::mutex> lk(p->mtx);
-    rc = run_segments(p, ref, srv, frame_stride, n_valid, window, nframes, (hipStream_t)stream);
-    if (rc) return rc;
-    return run_doppler(p, out, nframes, (hipStream_t)stream);
+    const int g = p->doppler == PRC_DOPPLER_COLUMN ? p->group : nframes;
+    for (int f0 = 0; f0 < nframes; f0 += g) {
+        const int nf = nframes - f0 < g ? nframes - f0 : g;
+        rc = run_segments(p, ref, srv, frame_stride, n_valid, window, f0, nf, f0, (hipStream_t)stream);
+        if (rc) return rc;
+        rc = run_doppler(p, (float2*)out + (int64_t)f0 * surf_elems(p), f0, nf, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return PRC_OK;
+}
+
+// fast_xambg for nref reference channels against ONE surveillance channel (range_doppler_processing.py:12-90 once
+// per pair): surface (i, b) of the workspace is illuminator i, frame b.
+extern "C" int prc_caf_execute_multi(prc_caf_plan* p, const void* const* refs_host, int32_t nref, const void* srv,
+                                     int64_t frame_stride, int64_t n_valid, const float* window,
+                                     void* const* outs_host, int32_t nframes, void* stream) {
+    PRC_REQUIRE(p && refs_host && outs_host && srv, PRC_EINVAL, "prc_caf_execute_multi: null argument");
+    PRC_REQUIRE(nref >= 1 && nref <= PRC_CAF_MAX_REFS, PRC_EINVAL, "prc_caf_execute_multi: nref=%d outside [1, %d]",
+                nref, PRC_CAF_MAX_REFS);
+    PRC_REQUIRE(nframes > 0 && (int64_t)nframes * nref <= p->desc.max_frames, PRC_EINVAL,
+                "prc_caf_execute_multi: nframes * nref = %lld surfaces exceed the plan's max_frames = %d",
+                (long long)nframes * nref, p->desc.max_frames);
+    PRC_REQUIRE(n_valid >= 0 && n_valid <= p->desc.n, PRC_ESHAPE,
+                "prc_caf_execute_multi: n_valid=%lld exceeds inputLen=%lld", (long long)n_valid, (long long)p->desc.n);
+    for (int i = 0; i < nref; ++i)
+        PRC_REQUIRE(refs_host[i] && outs_host[i], PRC_EINVAL, "prc_caf_execute_multi: null channel %d", i);
+    std::lock_guard<std::mutex> lk(p->mtx);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t se = surf_elems(p);
+    const bool shared = p->method == PRC_CAF_FFT4096 && p->doppler == PRC_DOPPLER_COLUMN && nref > 1 &&
+                        caf_team_multi_supported(p->desc.n, p->desc.range_bins, p->desc.freq_bins, p->ntaps, nref);
+    if (!shared) {
+        // one pass per illuminator (any method): same results, nothing shared
+        for (int i = 0; i < nref; ++i) {
+            const int g = p->doppler == PRC_DOPPLER_COLUMN ? p->group : nframes;
+            for (int f0 = 0; f0 < nframes; f0 += g) {
+                const int nf = nframes - f0 < g ? nframes - f0 : g;
+                int rc = run_segments(p, refs_host[i], srv, frame_stride, n_valid, window, f0, nf, f0, st);
+                if (rc) return rc;
+                rc = run_doppler(p, (float2*)outs_host[i] + (int64_t)f0 * se, f0, nf, st);
+                if (rc) return rc;
+            }
+        }
+        return PRC_OK;
+    }
+    // frames in groups of g: surfaces [i * g + b] of the workspace, the surveillance pieces transformed once per
+    // segment for all illuminators
+    int g = p->group / nref;
+    if (g < 1) g = 1;
+    for (int f0 = 0; f0 < nframes; f0 += g) {
+        const int nf = nframes - f0 < g ? nframes - f0 : g;
+        CafSegArgs a;
+        a.ref = nullptr;
+        a.srv = (const float2*)srv + (int64_t)f0 * frame_stride;
+        a.window = window;
+        a.taps = nullptr;
+        a.y = p->d_y2;
+        a.frame_stride = frame_stride;
+        a.n = p->desc.n;
+        a.n_valid = n_valid;
+        a.q = p->q;
+        a.ntaps = p->ntaps;
+        a.half = p->half;
+        a.range_bins = p->desc.range_bins;
+        a.freq_bins = p->desc.freq_bins;
+        a.y_layout = PRC_Y_JK;
+        const float2* refs[PRC_CAF_MAX_REFS];
+        for (int i = 0; i < nref; ++i) refs[i] = (const float2*)refs_host[i] + (int64_t)f0 * frame_stride;
+        int rc = caf_launch_fft_team_multi(a, refs, nref, (int64_t)nf * se, nf, st);
+        if (rc) return rc;
+        for (int i = 0; i < nref; ++i) {
+            rc = dop_launch(p->d_y2 + (int64_t)i * nf * se, (float2*)outs_host[i] + (int64_t)f0 * se, p->d_dop_tw,
+                            p->desc.freq_bins, p->desc.range_bins + 1, nf, st);
+            if (rc) return rc;
+        }
+    }
+    return PRC_OK;
 }

@@ -42,5 +42,12 @@ int caf_launch_fft_team(const CafSegArgs& a, int nframes, hipStream_t stream);
 bool caf_team_supported(int64_t n, int range_bins, int freq_bins, int ntaps_is_boxcar);
 double caf_team_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out);
 double caf_fft_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out);
+// nref reference channels against one surveillance channel in one launch (segments of <= 2 pieces): illuminator i's
+// surfaces go to y + i * y_ref_stride
+#define PRC_CAF_MAX_REFS 8
+int caf_launch_fft_team_multi(const CafSegArgs& a, const float2* const* refs, int nref, int64_t y_ref_stride,
+                              int nframes, hipStream_t stream);
+bool caf_team_multi_supported(int64_t n, int range_bins, int freq_bins, int64_t q1, int nref);
+double caf_team_multi_blocking(int64_t q1, int range_bins, int nref, int* nlb_out, int* lb_out);
 int caf_launch_transpose_jk_kj(const float2* src, float2* dst, int freq_bins, int cols, int nframes,
                                hipStream_t stream);

@@ -40,7 +40,12 @@
 #ifndef FT_NBUF
 #define FT_NBUF 2                       // exchange buffers: 2 = one barrier per forward transform; 1 = two barriers, half the LDS
 #endif
-#define FT_LDS_ELEMS (FT_TW1 + FT_NBUF * FT_BUF)             // float2 elements of LDS per workgroup (71 680 B with two buffers)
+#ifdef FT_TW2_LDS
+#define FT_TW2_ELEMS FT_P               // the 16 T2 constants of every thread live in LDS ([k2][t], 32 KB) instead of 32 VGPRs:
+#else                                   // for kernels held at two wavefronts per SIMD anyway (80 KB of LDS each)
+#define FT_TW2_ELEMS 0
+#endif
+#define FT_LDS_ELEMS (FT_TW1 + FT_NBUF * FT_BUF + FT_TW2_ELEMS)   // float2 elements of LDS per workgroup (71 680 B with two buffers)
 #define FT_GTAB (FT_TW1 + FT_P)         // global table: TW1 then W_4096^m, m = 0..4095
 
 struct FtLane {
@@ -49,7 +54,9 @@ struct FtLane {
     float2* wr;         // exchange base + 17 t           : write (t, rho) at wr[rho]            (+ FT_BUF for buffer 1)
     const float2* rdA;  // exchange base + 272 hi + lo    : row-private read (16 hi + m, lo) at rdA[17 m]
     const float2* rdB;  // exchange base + 17 lo + hi     : cross-wave read (16 m + lo, hi) at rdB[272 m]
-#ifdef FT_TW2_FACTORED
+#if defined(FT_TW2_LDS)
+    const float2* tw2l; // lds + FT_TW1 + FT_NBUF FT_BUF + t : W_4096^(lo (hi + 16 k2)) at tw2l[256 k2]
+#elif defined(FT_TW2_FACTORED)
     float2 tw2b;        // W_4096^(lo hi); the k2 part W_256^(lo k2) comes from the TW1 table (tw2t[16 k2])
     const float2* tw2t; // lds + lo
 #else
@@ -59,7 +66,9 @@ struct FtLane {
 
 // T2 twiddle of register k2 (forward sense; the inverse multiplies by its conjugate)
 __device__ __forceinline__ float2 ft_tw2(const FtLane& f, int k2) {
-#ifdef FT_TW2_FACTORED
+#if defined(FT_TW2_LDS)
+    return f.tw2l[FT_THREADS * k2];
+#elif defined(FT_TW2_FACTORED)
     return k2 == 0 ? f.tw2b : cmul(f.tw2b, f.tw2t[16 * k2]);
 #else
     return f.tw2[k2];
@@ -78,7 +87,14 @@ __device__ __forceinline__ FtLane ft_setup(float2* lds, const float2* __restrict
     f.rdA = x + 16 * FT_PITCH * hi + lo;
     f.rdB = x + FT_PITCH * lo + hi;
     lds[f.t] = gtab[f.t];               // FT_TW1 == FT_THREADS
-#ifdef FT_TW2_FACTORED
+#if defined(FT_TW2_LDS)
+    {
+        float2* tl = lds + FT_TW1 + FT_NBUF * FT_BUF + f.t;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) tl[FT_THREADS * k2] = gtab[FT_TW1 + ((lo * (hi + 16 * k2)) & (FT_P - 1))];
+        f.tw2l = tl;
+    }
+#elif defined(FT_TW2_FACTORED)
     f.tw2b = gtab[FT_TW1 + lo * hi];
     f.tw2t = lds + lo;
 #else

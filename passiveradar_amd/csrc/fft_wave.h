@@ -18,6 +18,9 @@
 #pragma once
 #include "common.h"
 
+// pure arithmetic helpers are host + device: tests/csrc/doppler_emul.cpp runs the Doppler kernel's phases on the CPU
+#define PRC_HD __host__ __device__ __forceinline__
+
 #define FFTW_P 1024
 #define FFTW_R 16                 // points per lane
 #define FFTW_PITCH 68             // float2 elements per LDS tile row
@@ -27,29 +30,29 @@
 #define FFTW_TW2S (16 * 4)        // the same times the quad sign sigma_j = sA_j sB_j (forward transform)
 #define FFTW_TABLE (FFTW_TW1 + FFTW_TW2 + FFTW_TW2S)
 
-__device__ __forceinline__ float2 f2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 f2sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+PRC_HD float2 f2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+PRC_HD float2 f2sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
 // multiply by -i (DIR = +1, forward) or +i (DIR = -1, inverse)
 template <int DIR>
-__device__ __forceinline__ float2 mul_mi(float2 a) {
+PRC_HD float2 mul_mi(float2 a) {
     return DIR > 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
 }
 // a * (c - i*DIR*s)
 template <int DIR>
-__device__ __forceinline__ float2 mul_cs(float2 a, float c, float s) {
+PRC_HD float2 mul_cs(float2 a, float c, float s) {
     return DIR > 0 ? make_float2(fmaf(a.y, s, a.x * c), fmaf(-a.x, s, a.y * c))
                    : make_float2(fmaf(-a.y, s, a.x * c), fmaf(a.x, s, a.y * c));
 }
 // a * t (forward) or a * conj(t) (inverse)
 template <int DIR>
-__device__ __forceinline__ float2 mul_tw(float2 a, float2 t) {
+PRC_HD float2 mul_tw(float2 a, float2 t) {
     return DIR > 0 ? make_float2(fmaf(-a.y, t.y, a.x * t.x), fmaf(a.x, t.y, a.y * t.x))
                    : make_float2(fmaf(a.y, t.y, a.x * t.x), fmaf(-a.x, t.y, a.y * t.x));
 }
 
 template <int DIR>
-__device__ __forceinline__ void bfly4(float2& x0, float2& x1, float2& x2, float2& x3) {
+PRC_HD void bfly4(float2& x0, float2& x1, float2& x2, float2& x3) {
     const float2 s02 = f2add(x0, x2), d02 = f2sub(x0, x2);
     const float2 s13 = f2add(x1, x3), d13 = f2sub(x1, x3);
     const float2 t = mul_mi<DIR>(d13);
@@ -61,7 +64,7 @@ __device__ __forceinline__ void bfly4(float2& x0, float2& x1, float2& x2, float2
 
 // In-register 16-point DFT, natural order in and out: v[k] = sum_n v[n] W_16^(DIR*n*k)
 template <int DIR>
-__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+PRC_HD void dft16(float2 (&v)[16]) {
     constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
     constexpr float S1 = 0.38268343236508977f;   // sin(pi/8)
     constexpr float RH = 0.70710678118654752f;   // sqrt(1/2)

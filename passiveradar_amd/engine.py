@@ -64,6 +64,17 @@ class CafPlan:
                                     self.n if n_valid is None else int(n_valid),
                                     _ptr(window), _ptr(out), int(nframes), stream))
 
+    def execute_multi(self, refs, srv, outs, nframes=1, frame_stride=None, n_valid=None, window=None, stream=None):
+        """prc_caf_execute_multi: every reference channel of ``refs`` against ONE surveillance channel in one call;
+        ``outs[i]`` receives what ``execute(refs[i], srv, ...)`` would write (len(refs) * nframes <= max_frames)."""
+        nref = len(refs)
+        rp = (C.c_void_p * nref)(*[_ptr(r) for r in refs])
+        op = (C.c_void_p * nref)(*[_ptr(o) for o in outs])
+        check(lib().prc_caf_execute_multi(self._h, rp, nref, _ptr(srv),
+                                          self.n if frame_stride is None else int(frame_stride),
+                                          self.n if n_valid is None else int(n_valid),
+                                          _ptr(window), op, int(nframes), stream))
+
     def execute_segments(self, ref, srv, nframes=1, frame_stride=None, n_valid=None, window=None,
                          stream=None):
         check(lib().prc_caf_execute_segments(self._h, _ptr(ref), _ptr(srv),

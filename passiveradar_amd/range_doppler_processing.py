@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib, engine
 
-__all__ = ["fast_xambg", "caf_plan_for", "set_default_methods"]
+__all__ = ["fast_xambg", "fast_xambg_multi", "caf_plan_for", "set_default_methods"]
 
 # Kernel selection used by fast_xambg (0 = let the plan decide).  Not part of the reference
 # signature; tests flip it to run the same cases through every kernel family.
@@ -21,7 +21,8 @@ _DEFAULTS = {"caf": _lib.CAF_AUTO, "doppler": _lib.DOPPLER_AUTO}
 
 
 def set_default_methods(caf=None, doppler=None):
-    """caf: 0 auto | 1 direct | 2 fft (1024-point) | 3 fft (4096-point team);  doppler: 0 auto | 1 rocfft."""
+    """caf: 0 auto | 1 direct | 2 fft (1024-point) | 3 fft (4096-point team);
+    doppler: 0 auto | 1 transpose + rocfft + shift | 2 one column-FFT kernel (freq_bins 256..4096, powers of two)."""
     if caf is not None:
         _DEFAULTS["caf"] = int(caf)
     if doppler is not None:
@@ -107,3 +108,64 @@ def fast_xambg(refChannel, srvChannel, rangeBins, freqBins, inputLen=None, windo
         d_win.upload(window)
     plan.execute(d_ref, d_srv, d_out, 1, n, n_in, d_win)
     return d_out.download((int(freqBins), int(rangeBins) + 1, 1), np.complex64)
+
+
+def fast_xambg_multi(refChannels, srvChannel, rangeBins, freqBins, inputLen=None, window=None, shortFilt=True):
+    """``[fast_xambg(r, srvChannel, ...) for r in refChannels]`` in one call: several illuminators against ONE
+    surveillance channel (BASELINE config 5).  The reference calls fast_xambg once per (reference, surveillance) pair
+    (range_doppler_processing.py:12-90); the pairs of one frame share the surveillance channel and the window, so the
+    device transforms the surveillance pieces once per segment for all of them (prc_caf_execute_multi).  Same argument
+    meaning, errors and per-surface result as fast_xambg; returns a list of (freqBins, rangeBins+1, 1) complex64."""
+    refs = list(refChannels)
+    if not refs:
+        return []
+    if len(refs) > _lib.CAF_MAX_REFS:
+        out = []
+        for i in range(0, len(refs), _lib.CAF_MAX_REFS):
+            out += fast_xambg_multi(refs[i:i + _lib.CAF_MAX_REFS], srvChannel, rangeBins, freqBins, inputLen, window,
+                                    shortFilt)
+        return out
+    for r in refs:
+        if tuple(r.shape) != tuple(srvChannel.shape):                         # :46-49
+            raise ValueError("Input vectors must have the same length")
+    n_in = int(srvChannel.shape[0])
+    n = n_in if inputLen is None else int(inputLen)
+    if n_in > n:
+        raise ValueError("index can't contain negative values")
+    if isinstance(window, (tuple, str)):
+        window = _named_window(window, n)
+    elif window is not None and not _lib.is_device_tensor(window):
+        window = np.ascontiguousarray(window, dtype=np.float32)
+        if window.shape[0] != n:
+            raise ValueError(f"operands could not be broadcast together with shapes ({n},) ({window.shape[0]},)")
+    nref, F, R = len(refs), int(freqBins), int(rangeBins)
+    if _lib.is_device_tensor(srvChannel):
+        import torch
+        dev = srvChannel.device
+        with torch.cuda.device(dev):
+            st = _lib.torch_stream_ptr(dev)
+            plan = caf_plan_for(n, R, F, shortFilt, max_frames=nref, stream=st)
+            srv = srvChannel.to(torch.complex64).contiguous()
+            rr = [r.to(device=dev, dtype=torch.complex64).contiguous() for r in refs]
+            win = None
+            if window is not None:
+                win = window if _lib.is_device_tensor(window) else torch.from_numpy(window)
+                win = win.to(device=dev, dtype=torch.float32).contiguous()
+            outs = [torch.empty((F, R + 1, 1), dtype=torch.complex64, device=dev) for _ in refs]
+            plan.execute_multi(rr, srv, outs, 1, n, n_in, win, stream=st)
+        return outs
+    plan = caf_plan_for(n, R, F, shortFilt, max_frames=nref)
+    st = engine.staging()
+    d_srv = st.get("caf_srv", 8 * n_in)
+    d_srv.upload(np.ascontiguousarray(srvChannel, dtype=np.complex64))
+    d_refs = st.get("caf_refs", 8 * n_in * nref)
+    d_outs = st.get("caf_outs", 8 * F * (R + 1) * nref)
+    for i, r in enumerate(refs):
+        d_refs.upload(np.ascontiguousarray(r, dtype=np.complex64), offset_bytes=8 * n_in * i)
+    d_win = None
+    if window is not None:
+        d_win = st.get("caf_win", 4 * n)
+        d_win.upload(window)
+    plan.execute_multi([d_refs.ptr + 8 * n_in * i for i in range(nref)], d_srv,
+                       [d_outs.ptr + 8 * F * (R + 1) * i for i in range(nref)], 1, n, n_in, d_win)
+    return [d_outs.download((F, R + 1, 1), np.complex64, offset_bytes=8 * F * (R + 1) * i) for i in range(nref)]

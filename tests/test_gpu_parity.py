@@ -637,3 +637,134 @@ def test_caf_auto_picks_the_team_kernel_for_wide_spans():
     assert caf_plan_for(5000000, 1024, 1024).method == _lib.CAF_FFT4096       # config 3
     assert caf_plan_for(1 << 23, 2048, 2048).method == _lib.CAF_FFT4096       # config 5
     assert caf_plan_for(4096, 7, 64).method == _lib.CAF_FFT
+
+
+# ---- Doppler stage: one column-FFT kernel (doppler_col.h) vs the rocFFT path vs the oracle -----------------------
+@pytest.fixture(params=["column", "rocfft"])
+def doppler_method(request):
+    from passiveradar_amd import range_doppler_processing as rdp
+    rdp.set_default_methods(doppler={"rocfft": 1, "column": 2}[request.param])
+    yield request.param
+    rdp.set_default_methods(doppler=0)
+
+
+@pytest.mark.parametrize("n,R,F,caf", [(65536, 40, 256, 2), (1 << 16, 300, 512, 2), (1 << 17, 33, 1024, 1),
+                                      (1 << 18, 129, 2048, 2), (1 << 18, 7, 4096, 1), (1 << 17, 1500, 512, 3)])
+def test_doppler_methods_vs_oracle(n, R, F, caf, doppler_method):
+    """every column-FFT size (256 ... 4096) behind every segment kernel, ragged column tiles, against the oracle"""
+    from passiveradar_amd import range_doppler_processing as rdp
+    ref, srv = scene.make_scene(n, 1e5, R, 515 + F + R)
+    w = np.kaiser(n, 5.0)
+    exp = O.fast_xambg(ref, srv, R, F, n, w)
+    rdp.set_default_methods(caf=caf)
+    try:
+        out = rdp.fast_xambg(ref, srv, R, F, n, w)
+    finally:
+        rdp.set_default_methods(caf=0)
+    assert rel_err(out, exp) < TIGHT
+
+
+def test_auto_picks_the_column_doppler_kernel():
+    from passiveradar_amd import _lib
+    from passiveradar_amd.range_doppler_processing import caf_plan_for
+    assert caf_plan_for(2400000, 256, 512).doppler == _lib.DOPPLER_COLUMN
+    assert caf_plan_for(1 << 23, 2048, 2048).doppler == _lib.DOPPLER_COLUMN
+    assert caf_plan_for(6000, 6, 64).doppler == _lib.DOPPLER_ROCFFT
+    assert caf_plan_for(5000, 4, 51).doppler == _lib.DOPPLER_ROCFFT
+
+
+def test_batched_frames_in_cache_sized_groups(monkeypatch):
+    """prc_caf_execute alternates segment sums and Doppler transforms over groups of surfaces; a budget of a fraction
+    of a surface forces one-frame groups, and the maps must not depend on the grouping"""
+    import torch
+    from passiveradar_amd import engine
+    n, R, F, nf = 1 << 15, 60, 256, 7
+    ref, srv = scene.make_scene(n // 2 * (nf + 1), 1e5, R, 808)
+    a, s = torch.from_numpy(ref).cuda(), torch.from_numpy(srv).cuda()
+    outs = []
+    for mb in ("0.01", "0.3", "1000"):
+        monkeypatch.setenv("PRC_CAF_GROUP_MB", mb)
+        plan = engine.CafPlan(n, R, F, nf)
+        out = torch.zeros((nf, F, R + 1), dtype=torch.complex64, device="cuda")
+        plan.execute(a, s, out, nf, n // 2, n, None)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+        plan.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    exp = O.fast_xambg(ref[n // 2 * 3:n // 2 * 3 + n], srv[n // 2 * 3:n // 2 * 3 + n], R, F, n, None)[:, :, 0]
+    assert rel_err(outs[0][3], exp) < TIGHT
+
+
+# ---- several illuminators against one surveillance channel: prc_caf_execute_multi --------------------------------
+@pytest.mark.parametrize("n,R,F,nref,caf,win,n_in", [
+    (131072, 2048, 32, 4, 0, True, None),     # config-5 segment shape (two pieces of 2048 + the direct tail sample)
+    (65536, 1024, 8, 3, 0, True, None),       # config-3 lag span: pieces of 3072, two per segment
+    (65536, 300, 16, 2, 3, False, None),      # forced 4096-point method, one full piece + a remainder piece
+    (1 << 18, 300, 16, 3, 3, True, None),     # five pieces per segment: the illuminators take turns (nothing shared)
+    (40000, 9000, 2, 2, 3, False, None),      # several lag blocks, wrap of srv inside pieces
+    (20000, 700, 3, 4, 3, True, 17000),       # zero-pad branch: n_valid < n
+    (32768, 64, 256, 5, 0, True, None),       # 1024-point method: the fallback of the multi call, column Doppler
+    (6000, 6, 64, 2, 0, True, None),          # rocFFT Doppler path
+])
+def test_caf_multi_equals_single_calls_and_oracle(n, R, F, nref, caf, win, n_in):
+    """prc_caf_execute_multi (every reference channel against ONE surveillance channel in one call) returns what one
+    fast_xambg per pair returns (range_doppler_processing.py:81-89) -- and what the oracle computes"""
+    from passiveradar_amd import range_doppler_processing as rdp
+    m = n if n_in is None else n_in
+    refs, srv = scene.make_multi_scene(m, 1e5, min(R, 200), [7000 + 13 * i + n + R for i in range(nref)])
+    w = np.kaiser(n, 5.0) if win else None
+    rdp.set_default_methods(caf=caf)
+    try:
+        outs = rdp.fast_xambg_multi(refs, srv, R, F, n, w)
+        singles = [rdp.fast_xambg(r, srv, R, F, n, w) for r in refs]
+    finally:
+        rdp.set_default_methods(caf=0)
+    assert len(outs) == nref
+    for i in range(nref):
+        assert outs[i].shape == (F, R + 1, 1) and outs[i].dtype == np.complex64
+        assert rel_err(outs[i], singles[i]) < 2e-6, i            # same arithmetic up to the order of two sums
+        assert rel_err(outs[i], O.fast_xambg(refs[i], srv, R, F, n, w)) < TIGHT, i
+
+
+def test_caf_multi_batched_overlapped_frames_and_errors():
+    import torch
+    from passiveradar_amd import engine
+    from passiveradar_amd.range_doppler_processing import fast_xambg_multi
+    n, R, F, nf, nref = 1 << 16, 1024, 8, 3, 2
+    refs, srv = scene.make_multi_scene(n // 2 * (nf + 1), 1e5, 100, [91, 92])
+    dr = [torch.from_numpy(r).cuda() for r in refs]
+    ds = torch.from_numpy(srv).cuda()
+    plan = engine.CafPlan(n, R, F, nf * nref)
+    outs = [torch.zeros((nf, F, R + 1), dtype=torch.complex64, device="cuda") for _ in range(nref)]
+    plan.execute_multi(dr, ds, outs, nf, n // 2, n, None)
+    torch.cuda.synchronize()
+    for i in range(nref):
+        for b in range(nf):
+            exp = O.fast_xambg(refs[i][b * n // 2:b * n // 2 + n], srv[b * n // 2:b * n // 2 + n], R, F, n, None)
+            assert rel_err(outs[i][b].cpu().numpy(), exp[:, :, 0]) < TIGHT, (i, b)
+    with pytest.raises(ValueError):
+        plan.execute_multi(dr, ds, outs, nf + 1, n // 2, n, None)          # surfaces beyond max_frames
+    with pytest.raises(ValueError):
+        fast_xambg_multi([refs[0][:100]], srv, R, F)                       # length mismatch (:46-49)
+    # device tensors in, device tensors out
+    dd = fast_xambg_multi([r[:n] for r in dr], ds[:n], R, F)
+    assert rel_err(dd[1].cpu().numpy(), O.fast_xambg(refs[1][:n], srv[:n], R, F)) < TIGHT
+
+
+def test_caf_cfg5_digest_multi():
+    """BASELINE config 5 at full size (N = 2^23, 2048 x 2048, four illuminators against one surveillance channel)
+    against digests of the REFERENCE's own fast_xambg, one per illuminator (oracle/gen_golden.py
+    caf_cfg5_digest_case); the multi call, which shares the surveillance transforms"""
+    from scipy.signal import get_window
+    from passiveradar_amd.range_doppler_processing import fast_xambg_multi
+    g = load_golden("caf_cfg5_digest")
+    n, R, F = int(g["N"]), int(g["R"]), int(g["F"])
+    refs, srv = scene.make_multi_scene(n, float(g["fs"]), R, [int(sd) for sd in g["seeds"]])
+    outs = fast_xambg_multi(refs, srv, R, F, n, get_window(("kaiser", 5.0), n))
+    for i, out in enumerate(outs):
+        out = out[:, :, 0]
+        peak = float(g[f"ill{i}_peak"])
+        assert np.abs(out[::16, ::16] - g[f"ill{i}_sub"]).max() / peak < TOL, i
+        assert np.abs(out.ravel()[g[f"ill{i}_top_idx"]] - g[f"ill{i}_top_val"]).max() / peak < TOL, i
+        assert np.abs(out.sum(axis=0) - g[f"ill{i}_col_sums"]).max() / (peak * np.sqrt(F)) < TOL, i
+        assert np.abs(out.sum(axis=1) - g[f"ill{i}_row_sums"]).max() / (peak * np.sqrt(R + 1)) < TOL, i

@@ -259,3 +259,25 @@ def test_committed_bench_line_follows_the_contract(tag):
         assert d["timed_seconds"] >= 5.0                                       # long enough for the driver's sampler
         assert c["cores"] == c["workers"] >= 1 and c["one_core_value"] > 0     # all-cores figure is measured, not scaled
         assert r["traffic"] is None or "profiles/" in r["traffic_source"]
+
+
+@pytest.mark.parametrize("F", [256, 512, 1024, 2048, 4096])
+def test_doppler_column_kernel_phases_on_the_cpu(F):
+    """the Doppler column-FFT kernel (passiveradar_amd/csrc/doppler_col.h) run phase by phase, thread by thread on
+    the host with its own index algebra, LDS slots and twiddle table (tests/csrc/doppler_emul.cpp): equals
+    fftshift(fft(y, axis=0), axes=0) of range_doppler_processing.py:89 for ragged column counts and several frames"""
+    import ctypes
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    lib = os.path.join(here, "libdopemul.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", here, "libdopemul.so"])
+    h = ctypes.CDLL(lib)
+    h.dop_emul.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    rng = np.random.default_rng(F)
+    for cols, nf in ((1, 1), (37, 2), (65, 1)):
+        y = (rng.standard_normal((nf, F, cols)) + 1j * rng.standard_normal((nf, F, cols))).astype(np.complex64)
+        out = np.full_like(y, np.nan)
+        assert h.dop_emul(F, y.ctypes.data, out.ctypes.data, cols, nf) == 0
+        exp = np.fft.fftshift(np.fft.fft(y.astype(np.complex128), axis=1), axes=1)
+        assert np.abs(out - exp).max() / np.abs(exp).max() < 1e-6
