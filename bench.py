@@ -128,7 +128,7 @@ def _cpu_frame_worker(args):
     return t_caf, t_cl
 
 
-def cpu_baseline(workload, max_workers=32):
+def cpu_baseline(workload, max_workers=32, asis=False):
     """(i) one core, bounded sample; (ii) all cores: one frame per worker process on min(cores, 32) workers."""
     import multiprocessing as mp
     fs, n, R, F, clutter, _ = WORKLOADS[workload]
@@ -181,6 +181,13 @@ def main():
                     help="N>1: prc = prc_gather_frames (RCCL through the C ABI), torch = torch.distributed.gather, "
                          "auto = prc when every rank could create the communicator, else torch")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-multi", action="store_true",
+                    help="cfg5: one fast_xambg pass per illuminator instead of the shared-surveillance multi call")
+    ap.add_argument("--cpu-workers", default="32",
+                    help="worker processes of the all-cores cpu_baseline leg: a number or 'all' (every host core)")
+    ap.add_argument("--cpu-asis", action="store_true",
+                    help="also time the reference CAF as it ships (SciPy's per-lag np.roots call left in) on a few lag "
+                         "columns, scaled: the transparency figure of SURVEY 8d")
     ap.add_argument("--no-clutter", action="store_true", help="CAF only (reported as a different metric)")
     args = ap.parse_args()
 
@@ -228,7 +235,9 @@ def main():
     batch = min(sub, max(nframes, 1))
     be = prstream.HipBackend(n, R, F, fs, clutter=clutter, batch=batch, device=device,
                              caf_method=args.caf_method, overlap=not args.no_overlap,
-                             ls_method=args.ls_method, nsub=args.nsub, ls_streams=args.ls_streams)
+                             ls_method=args.ls_method, nsub=args.nsub, ls_streams=args.ls_streams,
+                             nref=len(my_ills) if nill > 1 else 1)
+    multi = nill > 1 and len(my_ills) > 1 and not args.no_multi
 
     # ---- synthetic IQ resident in HBM --------------------------------------------------------------
     seed0 = 20260926 + (rank if not strong else 0)
@@ -325,9 +334,14 @@ def main():
         stepno[0] += 1
         if gathered[p] is not None:
             torch.cuda.current_stream().wait_event(gathered[p])
-        for r_i, out in zip(refs, outs[p]):          # further illuminators share the surveillance channel
-            if nframes:
-                be.run(r_i, srv_pad, nlocal, first, nframes, out=out)
+        if multi and nframes:
+            # every illuminator of this rank against the shared surveillance channel in ONE call per sub-batch:
+            # prc_caf_execute_multi transforms the surveillance pieces once per segment for all of them
+            be.frames_multi(refs, srv_pad, first, nframes, outs[p])
+        else:
+            for r_i, out in zip(refs, outs[p]):      # one fast_xambg pass per illuminator
+                if nframes:
+                    be.run(r_i, srv_pad, nlocal, first, nframes, out=out)
         if gather_mode != "none":
             if strong:
                 gather(outs[p][0][:nframes])
@@ -364,10 +378,13 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    rank_seconds = [dt]
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                 # every rank's own clock around the same K steps
+        rank_seconds = [float(t.item()) for t in every]
+        dt = max(rank_seconds)
     value = frames_per_step_total * steps / dt      # a multi-illuminator frame = all its CAF surfaces
 
     # ---- per-kernel timing with HIP events on the launch stream (rank 0) --------------------
@@ -489,6 +506,10 @@ def main():
                        "doppler_method": {1: "rocfft"}.get(dp, dp),
                        "parallelism": par},
             "timed_seconds": dt,
+            # which code moved the maps (prc = prc_gather_frames: RCCL send/recv group through the C ABI; torch =
+            # torch.distributed.gather; none = single GPU or surfaces stay put) and every rank's own clock
+            "gather_path": gather_mode, "rccl_version": _lib.rccl_version() if gather_mode == "prc" else None,
+            "rank_ms_per_step": [t / steps * 1e3 for t in rank_seconds],
             "hbm_algorithmic_GBps": per_frame_bytes * value / world / 1e9,
             "hbm_frac_of_peak": per_frame_bytes * value / world / 1e9 / HBM_PEAK_GBS,
             "hbm_frac_of_copy_ceiling": per_frame_bytes * value / world / 1e9 / 6290.0,   # MI355X_MICROARCH.md: ~6.3 TB/s achievable
@@ -502,7 +523,8 @@ def main():
         result["caf_only_frames_per_s_per_gpu"] = nb / (caf_ms * 1e-3)
         result["caf_only_hbm_frac"] = caf_bytes * nb / (caf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if world == 1 and not args.no_cpu:
-            cb = cpu_baseline(wl)
+            cb = cpu_baseline(wl, max_workers=(os.cpu_count() or 1) if args.cpu_workers == "all" else int(args.cpu_workers),
+                              asis=args.cpu_asis)
             result["cpu_baseline"] = cb
             result["speedup_vs_cpu_all_cores_measured"] = value / cb["value"]
             result["speedup_vs_cpu_1core"] = value / cb["one_core_value"]

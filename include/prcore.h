@@ -105,9 +105,10 @@ int prc_caf_execute(prc_caf_plan* plan, const void* ref, const void* srv, int64_
 /* fast_xambg for nref (<= 8) reference channels against ONE surveillance channel in one call -- a multi-illuminator
  * frame (range_doppler_processing.py:12-90 once per pair; :81-86 is the per-pair unit): outs_host[i] receives what
  * prc_caf_execute(plan, refs_host[i], srv, ...) would write.  refs_host / outs_host are HOST arrays of nref DEVICE
- * pointers.  nframes * nref surfaces must fit the plan's max_frames.  With the 4096-point method and segments of at
- * most two pieces (wide range spans: BASELINE configs 3 and 5) the surveillance pieces are transformed once per
- * segment for all illuminators; otherwise the illuminators take turns through the single-reference kernels. */
+ * pointers.  nframes * nref surfaces must fit the plan's max_frames.  By default the illuminators take turns through
+ * the single-reference kernels (measured fastest on MI355X); with PRC_CAF_MULTI_MODE=1 in the environment, the
+ * 4096-point method and segments of at most two pieces (wide range spans: BASELINE configs 3 and 5) the surveillance
+ * pieces are transformed once per segment for all illuminators (same results to the order of two sums). */
 int prc_caf_execute_multi(prc_caf_plan* plan, const void* const* refs_host, int32_t nref, const void* srv,
                           int64_t frame_stride, int64_t n_valid, const float* window, void* const* outs_host,
                           int32_t nframes, void* stream);

@@ -87,7 +87,7 @@ static int build_rocfft(prc_caf_plan* p, int frames) {
 // surfaces per segment/Doppler round: as many as keep the slow-time buffer inside the Infinity Cache next to
 // the inputs that stream through it (PRC_CAF_GROUP_MB overrides the budget; measured in DESIGN.md)
 static int pick_group(const prc_caf_desc* d) {
-    double mb = 96.0;
+    double mb = 1e9;
     if (const char* e = getenv("PRC_CAF_GROUP_MB")) {
         const double v = atof(e);
         if (v > 0) mb = v;
@@ -97,6 +97,15 @@ static int pick_group(const prc_caf_desc* d) {
     if (g < 1) g = 1;
     if (g > d->max_frames) g = d->max_frames;
     return g;
+}
+
+// How prc_caf_execute_multi runs several illuminators: 0 = "turns", one single-reference pass per illuminator (three
+// wavefronts per SIMD; the default: measured fastest on MI355X); 1 = "shared", the kernel of
+// caf_fft_team_multi.hip that transforms the surveillance pieces once per segment for all illuminators (14 instead of 20
+// transforms per four-illuminator segment, but two wavefronts per SIMD).  PRC_CAF_MULTI_MODE overrides (A/B runs, tests).
+static int multi_mode() {
+    const char* e = getenv("PRC_CAF_MULTI_MODE");
+    return e ? atoi(e) : 0;
 }
 
 extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
@@ -332,7 +341,7 @@ extern "C" int prc_caf_execute_multi(prc_caf_plan* p, const void* const* refs_ho
     std::lock_guard<std::mutex> lk(p->mtx);
     hipStream_t st = (hipStream_t)stream;
     const int64_t se = surf_elems(p);
-    const bool shared = p->method == PRC_CAF_FFT4096 && p->doppler == PRC_DOPPLER_COLUMN && nref > 1 &&
+    const bool shared = multi_mode() == 1 && p->method == PRC_CAF_FFT4096 && p->doppler == PRC_DOPPLER_COLUMN && nref > 1 &&
                         caf_team_multi_supported(p->desc.n, p->desc.range_bins, p->desc.freq_bins, p->ntaps, nref);
     if (!shared) {
         // one pass per illuminator (any method): same results, nothing shared

@@ -4,36 +4,55 @@
 #include "doppler_col.h"
 #include <math.h>
 
+// One tile per workgroup.  (A persistent, register-double-buffered form -- the next tile's loads in flight under the
+// current tile's transform -- measured SLOWER on MI355X at every size, 0.447 vs 0.363 ms per 16 config-5 surfaces: the
+// hardware's own queue of waiting workgroups overlaps tiles better than 32 more VGPRs per thread do.)
+// Workgroups reach the XCDs round-robin in launch order and every XCD has its own L2: workgroup b takes tile
+// (b % 8) * per_xcd + b / 8, so an XCD works through one contiguous run of tiles -- neighbouring tiles split 128-byte
+// lines of y and out between them.
 template <int F>
 __global__ __launch_bounds__(DopCfg<F>::THREADS) void doppler_col_kernel(const float2* __restrict__ y,
                                                                          float2* __restrict__ out,
-                                                                         const float2* __restrict__ tw, int cols) {
+                                                                         const float2* __restrict__ tw, int cols,
+                                                                         int tiles, int total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dop_smem[];
     float2* lds = reinterpret_cast<float2*>(dop_smem);
-    constexpr int Q = DopCfg<F>::Q, KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3;
+    constexpr int Q = DopCfg<F>::Q, KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3, E = DopCfg<F>::E;
+    const int per_xcd = (total + 7) >> 3;
+    const int work = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+    if (work >= total) return;                                  // uniform
+    const int frame = work / tiles, tile = work - frame * tiles;
     const int c = threadIdx.x % KT, p = threadIdx.x / KT;
-    const int k = blockIdx.x * KT + c;
-    const bool live = k < cols;
-    const int64_t base = (int64_t)blockIdx.y * F * cols + k;
+    const int k = tile * KT + c;
+    // Raw buffer accesses: the per-frame base is uniform, a thread's part of the offset is ONE 32-bit VGPR, and the
+    // register's part (row r Q of the loads, the fftshift-ed output row of register m of the stores) is a uniform
+    // soffset -- no 64-bit per-lane addresses.  Columns beyond the surface get an out-of-range offset: their loads
+    // return zero and their stores are dropped by the hardware range check.
+    const unsigned row_bytes = (unsigned)cols * 8u;
+    const unsigned ld_thread = (unsigned)p * row_bytes;                              // row p of the tile's column
+    const unsigned st_thread = (unsigned)((p / F3) + 16 * (p % F3) * E) * row_bytes;  // row k1 + 16 g E
+    const unsigned limit = 0xFFFFFFF0u - 2u * (unsigned)F * row_bytes;
+    const unsigned cb = k < cols ? (unsigned)k * 8u : 0xFFFFFFF8u - ld_thread - st_thread;
+    const __amdgpu_buffer_rsrc_t ry = prc_rsrc(y + (int64_t)frame * F * cols, limit);
+    const __amdgpu_buffer_rsrc_t ro = prc_rsrc(out + (int64_t)frame * F * cols, limit);
     float2 x[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        x[r] = live ? y[base + (int64_t)(r * Q + p) * cols] : make_float2(0.f, 0.f);
-    dop_stage1<F>(x, tw, p);
+    for (int r = 0; r < 16; ++r) x[r] = prc_buf_load_c64(ry, ld_thread + cb, (unsigned)(r * Q) * row_bytes);
+    const DopTw t = dop_load_twiddles<F>(tw, p);
+    dop_stage1<F>(x, t);
     dop_write1<F>(x, lds, p, c);
     __syncthreads();
     dop_read1<F>(x, lds, p, c);
-    dop_stage2<F>(x, tw, p);
+    dop_stage2<F>(x, t);
     if (F3 > 1) {
         dop_write2<F>(x, lds, p, c);      // the slots this thread just read: no barrier in between
         __syncthreads();
         dop_read2<F>(x, lds, p, c);
         dop_stage3<F>(x);
     }
-    if (live) {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) out[base + (int64_t)dop_out_row<F>(p, m) * cols] = x[m];
-    }
+    for (int m = 0; m < 16; ++m)
+        prc_buf_store_c64(ro, st_thread + cb, (unsigned)dop_out_row_reg<F>(m) * row_bytes, x[m]);
 }
 
 void dop_make_table(float2* t, int F) {
@@ -58,8 +77,10 @@ static int dop_launch_t(const float2* y, float2* out, const float2* tw, int cols
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0 && dev < 16) attr_done[dev] = true;
     }
-    dim3 grid((unsigned)((cols + KT - 1) / KT), (unsigned)nframes);
-    hipLaunchKernelGGL((doppler_col_kernel<F>), grid, dim3(DopCfg<F>::THREADS), lds, stream, y, out, tw, cols);
+    const int tiles = (cols + KT - 1) / KT, total = tiles * nframes;
+    dim3 grid((unsigned)(((total + 7) / 8) * 8));
+    hipLaunchKernelGGL((doppler_col_kernel<F>), grid, dim3(DopCfg<F>::THREADS), lds, stream, y, out, tw, cols, tiles,
+                       total);
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }

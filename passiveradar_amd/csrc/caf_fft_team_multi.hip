@@ -1,0 +1,247 @@
+// Cross-ambiguity segment sums of SEVERAL reference channels against one surveillance channel on the 4096-point
+// team FFT (fft_team.h); single-reference kernel and the algorithm: caf_fft_team.hip.
+//
+// This translation unit keeps the 16 per-thread T2 twiddles of the team transform in LDS (FT_TW2_LDS): the kernel
+// holds two surveillance spectra, the accumulator and one reference piece in registers and is at two wavefronts per
+// SIMD either way, which leaves 80 KB of LDS per workgroup -- room for the 32 KB table that buys back 32 VGPRs.
+#ifndef FT_NBUF
+#define FT_NBUF 1
+#endif
+#include "caf_internal.h"
+#include "fft_team.h"
+#include "caf_team_tail.h"
+
+// ---- several reference channels against ONE surveillance channel (BASELINE config 5: four illuminators) ----------
+// fast_xambg is called once per (reference, surveillance) pair (range_doppler_processing.py:81-86 is the per-pair
+// unit), so the surveillance pieces of a segment are the same for every illuminator.  When a segment is at most two
+// pieces (configs 3 and 5), their spectra V0, V1 stay in registers while the illuminators take turns:
+//     per illuminator  U0, U1 forward, acc = conj(U0) V0 + conj(U1) V1, one inverse
+// = 2 + 3 nref transforms per segment instead of 5 nref (14 instead of 20 at config 5), the surveillance channel and
+// its lag-extended pieces read once.  Segments of more pieces go through the single-reference kernel once per
+// illuminator (same results, no sharing).
+struct CafTeamMultiArgs {
+    CafSegArgs s;                              // s.ref unused; s.y = surface block of illuminator 0
+    const float2* gtab;
+    const float2* refs[PRC_CAF_MAX_REFS];
+    int64_t y_ref_stride;                      // elements between the illuminators' surface blocks in y
+    int32_t nref;
+    int32_t piece, lagblk, nlagblk, segs;
+};
+
+#ifndef CAFT_MULTI_WAVES
+#define CAFT_MULTI_WAVES 2
+#endif
+// w = conj(u) * v
+__device__ __forceinline__ float2 cmul_conj_a(float2 u, float2 v) {
+    return make_float2(fmaf(u.y, v.y, u.x * v.x), fmaf(-u.y, v.x, u.x * v.y));
+}
+
+template <bool HAS_WIN>
+__global__ __launch_bounds__(FT_THREADS, CAFT_MULTI_WAVES) void caf_fft_team_multi_kernel(CafTeamMultiArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    const FtLane f = ft_setup(lds, a.gtab);
+    const int t = f.t;
+    const int b = blockIdx.y;
+    const float2* __restrict__ srv = a.s.srv + (int64_t)b * a.s.frame_stride;
+    const float* __restrict__ win = a.s.window;
+    const int N = (int)a.s.n, NV = (int)a.s.n_valid;
+    const int R = a.s.range_bins;
+    const int B = a.piece, LB = a.lagblk;
+    const unsigned vo8 = (unsigned)t * 8u, vo4 = (unsigned)t * 4u;
+    auto clampu = [](int x) { return x < 0 ? 0u : (unsigned)x; };
+    const float sc = 1.0f / (float)FT_P;
+
+    for (int sg = 0; sg < a.segs; ++sg) {
+        const int64_t j = (int64_t)blockIdx.x * a.segs + sg;
+        if (j >= a.s.freq_bins) break;                         // uniform
+        const int64_t n_hi64 = j * a.s.q + a.s.half;
+        const int64_t n_lo64 = n_hi64 - (a.s.ntaps - 1);
+        const int lo = n_lo64 < 0 ? 0 : (int)n_lo64;
+        const int hi = n_hi64 > N - 1 ? N - 1 : (int)n_hi64;
+        const int len = hi - lo + 1;
+        int tail = len % B;
+        if (tail > CAFT_TAIL_MAX || len < B) tail = 0;
+        const int hi_f = hi - tail;
+        // at most two pieces (checked on the host): [lo, lo + cnt0) and [lo + B, hi_f]
+        const int cnt0 = hi_f - lo + 1 < B ? hi_f - lo + 1 : B;
+        const int n1p = lo + B;
+        const int cnt1 = hi_f - n1p + 1;                       // <= B; <= 0: one piece
+        const bool two = cnt1 > 0;
+
+        for (int lb = 0; lb < a.nlagblk; ++lb) {
+            auto load_v = [&](float2 (&v)[16], int n0, int cnt) {
+                int start = n0 + lb * LB;
+                if (start >= N) start -= N;
+                const int want = cnt + LB - 1;
+                int c1 = want;
+                if (N - start < c1) c1 = N - start;
+                if (NV - start < c1) c1 = NV - start;
+                const __amdgpu_buffer_rsrc_t rv = prc_rsrc(srv + start, clampu(c1) * 8u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = prc_buf_load_c64(rv, vo8, 2048u * r);
+                const int over = start + want - N;
+                if (over > 0) {
+                    const __amdgpu_buffer_rsrc_t rw2 = prc_rsrc(srv, clampu(over < NV ? over : NV) * 8u);
+                    const unsigned voff = vo8 - (unsigned)(N - start) * 8u;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float2 w2 = prc_buf_load_c64(rw2, voff + 2048u * r, 0u);
+                        v[r].x += w2.x;
+                        v[r].y += w2.y;
+                    }
+                }
+            };
+#ifndef CAFT_MULTI_PREFETCH
+            auto load_u = [&](float2 (&u)[16], const float2* __restrict__ ref, int n0, int cnt) {
+                if (NV - n0 < cnt) cnt = NV - n0;
+                const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + n0, clampu(cnt) * 8u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[r] = prc_buf_load_c64(ru, vo8, 2048u * r);
+                if (HAS_WIN) {
+                    const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + n0, clampu(cnt) * 4u);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float w = prc_buf_load_f32(rw, vo4, 1024u * r);
+                        u[r].x *= w;
+                        u[r].y *= w;
+                    }
+                }
+            };
+#endif
+            float2 v0[16], v1[16];
+            // buffer schedule (fft_team.h: transforms alternate exchange buffers 0, 1, 0, ...; a sequence that restarts
+            // at buffer 0 is separated by ft_team_sync()):  V0<0> V1<1> sync | U0<0> U1<1> inv<0> sync | ...
+            load_v(v0, lo, cnt0);
+            ft4096_fwd<0>(v0, f);
+            if (two) {                                          // uniform
+                load_v(v1, n1p, cnt1);
+                ft4096_fwd<1>(v1, f);
+            }
+            if (FT_NBUF == 2) ft_team_sync();
+            const int L0 = lb * LB;
+#ifdef CAFT_MULTI_PREFETCH
+            // the reference pieces arrive one transform ahead of their use: the loads of step (i, piece) + 1 are issued
+            // before the transform of step (i, piece); past the last illuminator the descriptor is empty
+            float2 un[16];
+            float wn[16];
+            auto issue_u = [&](const float2* __restrict__ ref, int n0, int cnt) {
+                if (NV - n0 < cnt) cnt = NV - n0;
+                const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + n0, clampu(cnt) * 8u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) un[r] = prc_buf_load_c64(ru, vo8, 2048u * r);
+                if (HAS_WIN) {
+                    const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + n0, clampu(cnt) * 4u);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) wn[r] = prc_buf_load_f32(rw, vo4, 1024u * r);
+                }
+            };
+            issue_u(a.refs[0] + (int64_t)b * a.s.frame_stride, lo, cnt0);
+#endif
+            for (int i = 0; i < a.nref; ++i) {
+                const float2* __restrict__ ref = a.refs[i] + (int64_t)b * a.s.frame_stride;
+                float2* __restrict__ yrow = a.s.y + (int64_t)i * a.y_ref_stride +
+                                            ((int64_t)b * a.s.freq_bins + j) * (R + 1);
+                float2 u[16], acc[16];
+#ifdef CAFT_MULTI_PREFETCH
+                const bool more = i + 1 < a.nref;
+                const float2* __restrict__ refn = a.refs[more ? i + 1 : i] + (int64_t)b * a.s.frame_stride;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
+                if (two) issue_u(ref, n1p, cnt1);
+                else issue_u(refn, lo, more ? cnt0 : 0);
+#else
+                load_u(u, ref, lo, cnt0);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                ft4096_fwd<0>(u, f);
+#pragma unroll
+                for (int m = 0; m < 16; ++m) acc[m] = cmul_conj_a(u[m], v0[m]);
+                if (two) {
+#ifdef CAFT_MULTI_PREFETCH
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
+                    issue_u(refn, lo, more ? cnt0 : 0);
+#else
+                    load_u(u, ref, n1p, cnt1);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    ft4096_fwd<1>(u, f);
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) cmac_conj_a(acc[m], u[m], v1[m]);
+                    ft4096_inv<0>(acc, f);
+                } else {
+                    ft4096_inv<1>(acc, f);                      // one piece: U0<0> is followed by buffer 1
+                }
+                ft_team_sync();
+                __builtin_amdgcn_sched_barrier(0);
+                if (tail > 0) caft_tail<HAS_WIN>(acc, ref, srv, win, hi_f, tail, L0, LB, R, N, NV, t);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int within = 256 * r + t;
+                    const int lag = L0 + within;
+                    if (within < LB && lag <= R) yrow[R - lag] = make_float2(acc[r].x * sc, -acc[r].y * sc);
+                }
+            }
+        }
+    }
+}
+
+// Blocking for nref illuminators sharing the surveillance transforms: lag blocks whose segments are at most two pieces,
+// cost nlb (pieces + nref (pieces + 1)) transforms.  Returns a negative value when no such blocking exists.
+double caf_team_multi_blocking(int64_t q1, int range_bins, int nref, int* nlb_out, int* lb_out) {
+    double best = -1.0;
+    for (int nlb = 1; nlb <= 64; ++nlb) {
+        const int lb = (range_bins + nlb) / nlb;
+        if (lb > 3073) continue;
+        const int64_t Bp = FT_P + 1 - lb;
+        int64_t pieces = q1 / Bp;
+        const int64_t rest = q1 % Bp;
+        if (rest > CAFT_TAIL_MAX || pieces == 0) ++pieces;
+        if (pieces <= 2) {
+            const double cost = (double)nlb * ((double)pieces + (double)nref * ((double)pieces + 1.0));
+            if (best < 0 || cost < best) {
+                best = cost;
+                if (nlb_out) *nlb_out = nlb;
+                if (lb_out) *lb_out = lb;
+            }
+        }
+        if (lb <= 2) break;
+    }
+    return best;
+}
+
+bool caf_team_multi_supported(int64_t n, int range_bins, int freq_bins, int64_t q1, int nref) {
+    return nref >= 1 && nref <= PRC_CAF_MAX_REFS && caf_team_supported(n, range_bins, freq_bins, 1) &&
+           caf_team_multi_blocking(q1, range_bins, nref, nullptr, nullptr) > 0;
+}
+
+int caf_launch_fft_team_multi(const CafSegArgs& s, const float2* const* refs, int nref, int64_t y_ref_stride,
+                              int nframes, hipStream_t stream) {
+    CafTeamMultiArgs a;
+    a.s = s;
+    a.nref = nref;
+    a.y_ref_stride = y_ref_stride;
+    for (int i = 0; i < PRC_CAF_MAX_REFS; ++i) a.refs[i] = i < nref ? refs[i] : nullptr;
+    PRC_REQUIRE(caf_team_multi_blocking(s.ntaps, s.range_bins, nref, &a.nlagblk, &a.lagblk) > 0, PRC_EUNSUPPORTED,
+                "caf_launch_fft_team_multi: segments of more than two pieces");
+    a.piece = FT_P + 1 - a.lagblk;
+    int rc = ft_device_tables(&a.gtab);
+    if (rc) return rc;
+    const int64_t total = (int64_t)s.freq_bins * nframes;
+    a.segs = total >= 16384 ? 4 : (total >= 4096 ? 2 : 1);
+    dim3 grid((unsigned)((s.freq_bins + a.segs - 1) / a.segs), (unsigned)nframes);
+    const size_t lds = sizeof(float2) * FT_LDS_ELEMS;
+    PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s.window ? &caf_fft_team_multi_kernel<true>
+                                                                       : &caf_fft_team_multi_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (s.window)
+        hipLaunchKernelGGL((caf_fft_team_multi_kernel<true>), grid, dim3(FT_THREADS), lds, stream, a);
+    else
+        hipLaunchKernelGGL((caf_fft_team_multi_kernel<false>), grid, dim3(FT_THREADS), lds, stream, a);
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}
+

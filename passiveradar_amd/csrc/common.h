@@ -96,6 +96,12 @@ __device__ __forceinline__ float2 prc_buf_load_c64(__amdgpu_buffer_rsrc_t r, uns
     const prc_v2u x = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
     return make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
 }
+__device__ __forceinline__ void prc_buf_store_c64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 v) {
+    prc_v2u x;
+    x.x = __float_as_uint(v.x);
+    x.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(x, r, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ float prc_buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }

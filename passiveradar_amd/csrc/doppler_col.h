@@ -20,13 +20,21 @@
 #pragma once
 #include "fft_wave.h"
 
+// columns per workgroup at 1024 and 2048 bins (A/B builds override them: a narrower tile halves the LDS footprint and
+// lets a CU hold two workgroups, at the price of shorter row segments)
+#ifndef DOP_KT_1024
+#define DOP_KT_1024 8
+#endif
+#ifndef DOP_KT_2048
+#define DOP_KT_2048 8
+#endif
 template <int F>
 struct DopCfg {
     static_assert(F == 256 || F == 512 || F == 1024 || F == 2048 || F == 4096, "column FFT sizes: 256..4096");
     static constexpr int Q = F / 16;                 // threads per column
     static constexpr int F3 = F / 256;               // radix of the last stage: 1, 2, 4, 8, 16
     static constexpr int E = 16 / F3;                // last-stage transforms per thread
-    static constexpr int KT = F == 256 ? 32 : (F <= 1024 ? 16 : (F == 2048 ? 8 : 4));   // columns per workgroup
+    static constexpr int KT = F == 256 ? 32 : (F == 512 ? 16 : (F == 1024 ? DOP_KT_1024 : (F == 2048 ? DOP_KT_2048 : 4)));   // columns per workgroup
     static constexpr int THREADS = Q * KT;           // 512, 512, 1024, 1024, 1024
     static constexpr int LDS_ELEMS = (F + F / 16) * KT;
 };
@@ -54,50 +62,100 @@ PRC_HD void dop_dft8(float2* v) {               // natural order in and out
     v[3] = f2add(e3, o3); v[7] = f2sub(e3, o3);
 }
 
-// S1: x holds the 16 samples r Q + p of one column.  tw: W_F^m, m = 0..F-1
-template <int F>
-PRC_HD void dop_stage1(float2 (&x)[16], const float2* __restrict__ tw, int p) {
-    dft16<1>(x);
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) x[k1] = mul_tw<1>(x[k1], tw[p * k1]);
+// Twiddles.  Thread p needs W^(p k1), k1 = 1..15, after S1 and W^(16 b ka), ka = 1..15, after S2: fifteen gathers from
+// the table each, every one a dependent L1/L2 round trip when issued one by one (measured: that serialisation, not the
+// arithmetic, set the kernel's time).  Instead four table entries per stage -- exponents 1, 2, 4, 8 times the base -- are
+// loaded up front next to the data, and the other eleven are products of at most three of them (|error| <= 3 ulp).
+struct DopTw {
+    float2 s1[4];     // W_F^(p), W_F^(2p), W_F^(4p), W_F^(8p)
+    float2 s2[4];     // W_F^(16b), W_F^(32b), W_F^(64b), W_F^(128b)
+};
+PRC_HD float2 dop_cmul(float2 a, float2 b) {
+    return make_float2(fmaf(-a.y, b.y, a.x * b.x), fmaf(a.x, b.y, a.y * b.x));
 }
+template <int F>
+PRC_HD DopTw dop_load_twiddles(const float2* __restrict__ tw, int p) {
+    constexpr int F3 = DopCfg<F>::F3;
+    const int b = p % F3;
+    DopTw t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        t.s1[i] = tw[p << i];                    // 8 p < 8 Q = F/2
+        t.s2[i] = tw[(16 * b) << i];             // 128 b < 128 F3 = F/2
+    }
+    return t;
+}
+// x[k] *= w^k, k = 1..15, from w^1, w^2, w^4, w^8
+PRC_HD void dop_apply_powers(float2 (&x)[16], const float2 (&w)[4]) {
+    const float2 w1 = w[0], w2 = w[1], w4 = w[2], w8 = w[3];
+    const float2 w3 = dop_cmul(w1, w2), w5 = dop_cmul(w4, w1), w6 = dop_cmul(w4, w2);
+    const float2 w7 = dop_cmul(w4, w3);
+    x[1] = dop_cmul(x[1], w1);
+    x[2] = dop_cmul(x[2], w2);
+    x[3] = dop_cmul(x[3], w3);
+    x[4] = dop_cmul(x[4], w4);
+    x[5] = dop_cmul(x[5], w5);
+    x[6] = dop_cmul(x[6], w6);
+    x[7] = dop_cmul(x[7], w7);
+    x[8] = dop_cmul(x[8], w8);
+    x[9] = dop_cmul(x[9], dop_cmul(w8, w1));
+    x[10] = dop_cmul(x[10], dop_cmul(w8, w2));
+    x[11] = dop_cmul(x[11], dop_cmul(w8, w3));
+    x[12] = dop_cmul(x[12], dop_cmul(w8, w4));
+    x[13] = dop_cmul(x[13], dop_cmul(w8, w5));
+    x[14] = dop_cmul(x[14], dop_cmul(w8, w6));
+    x[15] = dop_cmul(x[15], dop_cmul(w8, w7));
+}
+
+// S1: x holds the 16 samples r Q + p of one column
+template <int F>
+PRC_HD void dop_stage1(float2 (&x)[16], const DopTw& t) {
+    dft16<1>(x);
+    dop_apply_powers(x, t.s1);
+}
+// LDS slots as ONE per-thread base plus a compile-time offset per register (so that a phase costs one address VGPR,
+// not sixteen): with Q a multiple of 16 and F3 a divisor of 16,
+//   X1 write  slot(k1 Q + p)          = [(p + p/16) KT + c]                    + k1 (17 Q / 16) KT
+//   X1 read   slot(k1' Q + a F3 + b)  = [(k1' 17 Q / 16 + b) KT + c]           + (a F3 + (a F3)/16) KT      (= X2 write)
+//   X2 read   slot(k1' Q + 16 g + m)  = [(k1' 17 Q / 16 + 17 g) KT + c]        + m KT
 template <int F>
 PRC_HD void dop_write1(const float2 (&x)[16], float2* lds, int p, int c) {
     constexpr int Q = DopCfg<F>::Q, KT = DopCfg<F>::KT;
+    float2* w = lds + (p + (p >> 4)) * KT + c;
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) lds[dop_slot(k1 * Q + p, KT, c)] = x[k1];
+    for (int k1 = 0; k1 < 16; ++k1) w[k1 * (Q + Q / 16) * KT] = x[k1];
+}
+template <int F>
+PRC_HD int dop_base1(int p, int c) {
+    constexpr int Q = DopCfg<F>::Q, KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3;
+    return ((p / F3) * (Q + Q / 16) + (p % F3)) * KT + c;
 }
 template <int F>
 PRC_HD void dop_read1(float2 (&x)[16], const float2* lds, int p, int c) {
-    constexpr int Q = DopCfg<F>::Q, KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3;
-    const int k1 = p / F3, b = p % F3;
+    constexpr int KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3;
+    const float2* r = lds + dop_base1<F>(p, c);
 #pragma unroll
-    for (int a = 0; a < 16; ++a) x[a] = lds[dop_slot(k1 * Q + a * F3 + b, KT, c)];
+    for (int a = 0; a < 16; ++a) x[a] = r[(a * F3 + ((a * F3) >> 4)) * KT];
 }
 template <int F>
-PRC_HD void dop_stage2(float2 (&x)[16], const float2* __restrict__ tw, int p) {
-    constexpr int F3 = DopCfg<F>::F3;
-    const int b = p % F3;
+PRC_HD void dop_stage2(float2 (&x)[16], const DopTw& t) {
     dft16<1>(x);
-    if (F3 > 1) {
-#pragma unroll
-        for (int ka = 1; ka < 16; ++ka) x[ka] = mul_tw<1>(x[ka], tw[16 * b * ka]);
-    }
+    if (DopCfg<F>::F3 > 1) dop_apply_powers(x, t.s2);
 }
 template <int F>
 PRC_HD void dop_write2(const float2 (&x)[16], float2* lds, int p, int c) {
-    constexpr int Q = DopCfg<F>::Q, KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3;
-    const int k1 = p / F3, b = p % F3;
+    constexpr int KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3;
+    float2* w = lds + dop_base1<F>(p, c);
 #pragma unroll
-    for (int ka = 0; ka < 16; ++ka) lds[dop_slot(k1 * Q + ka * F3 + b, KT, c)] = x[ka];
+    for (int ka = 0; ka < 16; ++ka) w[(ka * F3 + ((ka * F3) >> 4)) * KT] = x[ka];
 }
-// register e F3 + b2 <- idx k1 Q + (g E + e) F3 + b2
+// register e F3 + b2 <- idx k1 Q + (g E + e) F3 + b2 = k1 Q + 16 g + m
 template <int F>
 PRC_HD void dop_read2(float2 (&x)[16], const float2* lds, int p, int c) {
     constexpr int Q = DopCfg<F>::Q, KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3;
-    const int k1 = p / F3, g = p % F3;
+    const float2* r = lds + ((p / F3) * (Q + Q / 16) + 17 * (p % F3)) * KT + c;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) x[m] = lds[dop_slot(k1 * Q + g * 16 + m, KT, c)];
+    for (int m = 0; m < 16; ++m) x[m] = r[m * KT];
 }
 template <int F>
 PRC_HD void dop_stage3(float2 (&x)[16]) {
@@ -123,6 +181,16 @@ PRC_HD int dop_out_row(int p, int m) {
     const int e = m / F3, kb = m % F3;
     const int k = F3 == 1 ? k1 + 16 * m : k1 + 16 * (g * E + e) + 256 * kb;
     return k ^ (F / 2);
+}
+
+// dop_out_row(p, m) = [k1 + 16 g E] + dop_out_row_reg(m): the fftshift only flips the top bit of kb (of m when F3 = 1),
+// which belongs to the register, so the thread's and the register's parts of the output row add without a carry
+template <int F>
+PRC_HD int dop_out_row_reg(int m) {
+    constexpr int F3 = DopCfg<F>::F3;
+    if (F3 == 1) return 16 * (m ^ 8);
+    const int e = m / F3, kb = m % F3;
+    return 16 * e + 256 * (kb ^ (F3 / 2));
 }
 
 // host side (caf_doppler.hip): W_F^m table, does the column kernel take this size, launch

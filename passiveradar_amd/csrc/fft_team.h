@@ -117,12 +117,14 @@ __device__ __forceinline__ void ft4096_fwd(float2 (&x)[16], const FtLane& f) {
     dft16<1>(x);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) x[k1] = mul_tw<1>(x[k1], f.tw1[16 * k1]);
+#ifndef FT_EXP_NOX1
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) f.wr[T + k1] = x[k1];
     FT_BARRIER();
 #pragma unroll
     for (int m = 0; m < 16; ++m) x[m] = f.rdB[T + 16 * FT_PITCH * m];
     if (FT_NBUF == 1) FT_BARRIER();       // single buffer: every cross-wave read phase is closed by a barrier
+#endif
     dft16<1>(x);
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) x[k2] = mul_tw<1>(x[k2], ft_tw2(f, k2));
@@ -143,21 +145,25 @@ __device__ __forceinline__ void ft4096_inv(float2 (&x)[16], const FtLane& f) {
     constexpr int T = (FT_NBUF == 2 ? CUR : 0) * FT_BUF;
     if (FT_NBUF == 2) FT_BARRIER();       // the buffer must be quiet before the row-private exchange below
     dft16<-1>(x);
+#ifndef FT_EXP_NOX2
 #pragma unroll
     for (int j = 0; j < 16; ++j) f.wr[T + j] = x[j];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int m = 0; m < 16; ++m) x[m] = f.rdA[T + FT_PITCH * m];
     __builtin_amdgcn_wave_barrier();
+#endif
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) x[k2] = mul_tw<-1>(x[k2], ft_tw2(f, k2));
     dft16<-1>(x);
+#ifndef FT_EXP_NOX1
 #pragma unroll
     for (int m = 0; m < 16; ++m) f.wr[T + m] = x[m];
     FT_BARRIER();
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) x[k1] = f.rdB[T + 16 * FT_PITCH * k1];
     if (FT_NBUF == 1) FT_BARRIER();
+#endif
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) x[k1] = mul_tw<-1>(x[k1], f.tw1[16 * k1]);
     dft16<-1>(x);

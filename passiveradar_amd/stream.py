@@ -135,8 +135,9 @@ def shard_sizes(shard):
 
 
 def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, comm=None, stream=None):
-    """Gather per-rank frame blocks [m_r][F][R+1] (torch tensors, complex64) to global rank ``dst``.
-    Returns the full [nchunks][F][R+1] tensor on dst, None elsewhere.  ONE collective.
+    """Gather per-rank frame blocks [m_r][F][R+1] (torch tensors, complex64) to rank ``dst`` -- a rank of ``comm``
+    when a FrameComm is given (0 .. comm.world-1; torch.distributed is not touched), else a global
+    torch.distributed rank.  Returns the full [nchunks][F][R+1] tensor on dst, None elsewhere.  ONE collective.
 
     comm: a FrameComm -> prc_gather_frames (RCCL point-to-point group through the C ABI, ragged blocks
     land at their place, nothing is padded); it is enqueued on ``stream`` (a torch stream, default the
@@ -149,11 +150,18 @@ def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, com
     async_op=True returns ``(result_or_None, work)``: ``work.wait()`` before touching the result (and
     before reusing ``local``)."""
     import torch
-    import torch.distributed as dist
     if shard.world == 1:
         return (local, None) if async_op else local
     F, cols = local.shape[1], local.shape[2]
-    on_dst = dist.get_rank() == dst                     # global rank, also for sub-groups
+    if comm is not None:
+        # the C-ABI path knows nothing of torch.distributed: ranks, the root and the world are the communicator's own
+        # (a FrameComm built over a sub-group, or over any other side channel, numbers its ranks from 0)
+        if comm.world != shard.world:
+            raise ValueError(f"gather_frames: the communicator has {comm.world} ranks, the shard plan {shard.world}")
+        on_dst = comm.rank == dst
+    else:
+        import torch.distributed as dist
+        on_dst = dist.get_rank() == dst                 # global rank, also for sub-groups
     res = None
     if on_dst:
         res = out if out is not None else torch.empty((shard.nchunks, F, cols), dtype=torch.complex64,
@@ -221,10 +229,12 @@ class HipBackend:
     wavefronts busy), the VALU-bound CAF kernel of sub-batch k fills the chip.
     """
 
+    LS_HALO = 2        # spare blocks in every LS plan (the two halo chunks of a sharded stream)
+
     def __init__(self, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
                  doppler_bins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), clutter="ls",
                  batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, overlap=True,
-                 ls_method=0, nsub=1, ls_streams=3):
+                 ls_method=0, nsub=1, ls_streams=3, nref=1):
         import torch
         from . import engine
         from .range_doppler_processing import _named_window
@@ -237,6 +247,7 @@ class HipBackend:
         self.bins = tuple(float(b) for b in doppler_bins)
         self.clutter = clutter
         self.batch = int(batch)
+        self.nref = max(1, int(nref))      # reference channels per surveillance channel (run_multi / frames_multi)
         self.nlms_mu = float(nlms_mu)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         # LS launches of batch/nsub chunks.  Measured on MI355X (config 2, two LS chains in flight): 256-chunk launches
@@ -246,13 +257,16 @@ class HipBackend:
         # chunks per LS launch; NLMS is one wavefront per chunk, so splitting a batch would only idle SIMDs
         self.sub = -(-self.batch // max(int(nsub), 1)) if (self.overlap and clutter == "ls") else self.batch
         with torch.cuda.device(self.device):
-            self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch, caf_method, doppler_method)
+            self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch * self.nref, caf_method, doppler_method)
             # The LS chain of a sub-batch is a strictly sequential string of kernels, a third of them latency-bound
             # (one Levinson-Durbin per block, per-bin solves: a few wavefronts busy).  Several plans on as many streams
             # run alternate sub-batches concurrently, so one chain's solves sit under the others' HBM-bound passes
             # (measured at config 2: 1 chain 18.7 k frames/s, 2: 20.25 k, 3: 20.46 k, 4: 20.51 k).
             self.nls = max(1, int(ls_streams)) if (self.overlap and clutter == "ls") else 1
-            self.ls_plans = [engine.LsPlan(self.C, self.R, 10, False, self.sub, ls_method)
+            # LS_HALO spare blocks per plan: a shard of m frames filters m + 2 chunks (one halo chunk each side,
+            # plan_shard); when the last sub-batch would be no more than the halo it rides in the launch before it
+            # instead of paying a latency-bound chain of its own (config 4 at 8 ranks: 150 frames, 152 chunks)
+            self.ls_plans = [engine.LsPlan(self.C, self.R, 10, False, self.sub + self.LS_HALO, ls_method)
                              for _ in range(self.nls)] if clutter == "ls" else []
             self.ls = self.ls_plans[0] if self.ls_plans else None
             if isinstance(window, (tuple, str)):
@@ -333,10 +347,23 @@ class HipBackend:
         out = self._clean_target(srv_pad)
         # NLMS is one wavefront per hop chunk and needs no plan workspace: every local chunk goes into ONE launch
         # (a 256-stream launch would leave three SIMDs in four idle); LS launches are bounded by the plan's workspace
-        step = self.sub if self.clutter == "ls" else max(nlocal, 1)
         with self.torch.cuda.device(self.device):
-            for c0 in range(0, nlocal, step):
-                self._clean_range(ref_pad, srv_pad, out, c0, min(step, nlocal - c0), self._stream())
+            for c0, c1 in self._ls_ranges(nlocal):
+                self._clean_range(ref_pad, srv_pad, out, c0, c1 - c0, self._stream())
+        return out
+
+    def _ls_ranges(self, nlocal):
+        """[c0, c1) chunk ranges of the clutter launches: sub-batches of ``sub`` chunks, a remainder of at most
+        LS_HALO chunks folded into the launch before it; NLMS takes every chunk in one launch"""
+        if self.clutter != "ls":
+            return [(0, nlocal)] if nlocal > 0 else []
+        out, c0 = [], 0
+        while c0 < nlocal:
+            c1 = min(c0 + self.sub, nlocal)
+            if nlocal - c1 <= self.LS_HALO:
+                c1 = nlocal
+            out.append((c0, c1))
+            c0 = c1
         return out
 
     def frames(self, ref_pad, clean_pad, offsets_first, nframes, out=None, f_lo=0, f_hi=None, stream=None):
@@ -353,12 +380,37 @@ class HipBackend:
                                  self.window, self._stream() if stream is None else stream)
         return out
 
+    def frames_multi(self, ref_pads, clean_pad, offsets_first, nframes, outs=None, stream=None):
+        """fast_xambg of EVERY reference channel in ``ref_pads`` against the one (cleaned) surveillance stream, frame
+        by overlapped frame: a multi-illuminator frame (BASELINE config 5) through prc_caf_execute_multi, which
+        transforms the surveillance pieces once per segment for all illuminators.  Returns one
+        [nframes][F][R+1] tensor per reference channel."""
+        torch = self.torch
+        nref = len(ref_pads)
+        if nref > self.nref:
+            raise ValueError(f"frames_multi: {nref} reference channels, the backend was built for nref={self.nref}")
+        if outs is None:
+            outs = [torch.empty((nframes, self.F, self.R + 1), dtype=torch.complex64, device=self.device)
+                    for _ in ref_pads]
+        with torch.cuda.device(self.device):
+            for f0 in range(0, nframes, self.batch):
+                nb = min(self.batch, nframes - f0)
+                off = offsets_first + f0 * self.C
+                self.caf.execute_multi([r[off:] for r in ref_pads], clean_pad[off:], [o[f0:] for o in outs], nb,
+                                       self.C, self.cpi, self.window, self._stream() if stream is None else stream)
+        return outs
+
+    def run_multi(self, ref_pads, srv_pad, nlocal, offsets_first, nframes, outs=None, clutter_ref=0):
+        """clean (against reference channel ``clutter_ref``, when the backend has a canceller) + frames_multi"""
+        clean = self.clean(ref_pads[clutter_ref], srv_pad, nlocal)
+        return self.frames_multi(ref_pads, clean, offsets_first, nframes, outs)
+
     def run(self, ref_pad, srv_pad, nlocal, offsets_first, nframes, out=None):
         """clean + frames for one resident shard.  With ``overlap`` the LS chain runs sub-batch by
         sub-batch on one stream and the CAF of every frame whose three chunks are already clean
         follows on a second stream (frame j needs local chunk j + offsets_first/C + 1).
         out: optional preallocated [>= nframes][F][R+1] complex64 tensor for the maps."""
-        if not self.overlap or nlocal <= self.sub:
+        if not self.overlap or nlocal <= self.sub + self.LS_HALO:
             clean = self.clean(ref_pad, srv_pad, nlocal)
             return self.frames(ref_pad, clean, offsets_first, nframes, out)
         import ctypes
@@ -366,15 +418,14 @@ class HipBackend:
         clean = self._clean_target(srv_pad)
         if out is None:
             out = torch.empty((nframes, self.F, self.R + 1), dtype=torch.complex64, device=self.device)
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(self.device)
         for st in self.s_ls_all:
             st.wait_stream(main)
         self.s_caf.wait_stream(main)
         first_chunk = offsets_first // self.C
         done = 0
         with torch.cuda.device(self.device):
-            for idx, c0 in enumerate(range(0, nlocal, self.sub)):
-                c1 = min(c0 + self.sub, nlocal)
+            for idx, (c0, c1) in enumerate(self._ls_ranges(nlocal)):
                 k = idx % self.nls
                 st = self.s_ls_all[k]
                 self._clean_range(ref_pad, srv_pad, clean, c0, c1 - c0, ctypes.c_void_p(st.cuda_stream),

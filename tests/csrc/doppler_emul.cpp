@@ -29,14 +29,14 @@ static int emul(const float2* y, float2* out, int cols, int nframes) {
                 float2(&x)[16] = X(t);
                 for (int r = 0; r < 16; ++r)
                     x[r] = k < cols ? y[((int64_t)fr * F + r * Q + p) * cols + k] : make_float2(0.f, 0.f);
-                dop_stage1<F>(x, tw.data(), p);
+                dop_stage1<F>(x, dop_load_twiddles<F>(tw.data(), p));
                 dop_write1<F>(x, lds.data(), p, c);
             }
             for (int t = 0; t < NT; ++t) {                               // after the first barrier
                 const int c = t % KT, p = t / KT;
                 float2(&x)[16] = X(t);
                 dop_read1<F>(x, lds.data(), p, c);
-                dop_stage2<F>(x, tw.data(), p);
+                dop_stage2<F>(x, dop_load_twiddles<F>(tw.data(), p));
                 if (F3 > 1) dop_write2<F>(x, lds.data(), p, c);           // in place: only slots this thread read
             }
             for (int t = 0; t < NT; ++t) {                               // after the second barrier
@@ -47,8 +47,12 @@ static int emul(const float2* y, float2* out, int cols, int nframes) {
                     dop_stage3<F>(x);
                 }
                 if (k < cols)
-                    for (int m = 0; m < 16; ++m)
-                        out[((int64_t)fr * F + dop_out_row<F>(p, m)) * cols + k] = x[m];
+                    for (int m = 0; m < 16; ++m) {
+                        // the kernel splits the row into a per-thread and a per-register part (no carry between them)
+                        const int row = (p / F3) + 16 * (p % F3) * DopCfg<F>::E + dop_out_row_reg<F>(m);
+                        if (row != dop_out_row<F>(p, m)) return -2;
+                        out[((int64_t)fr * F + row) * cols + k] = x[m];
+                    }
             }
         }
     return 0;

@@ -706,10 +706,13 @@ def test_batched_frames_in_cache_sized_groups(monkeypatch):
     (32768, 64, 256, 5, 0, True, None),       # 1024-point method: the fallback of the multi call, column Doppler
     (6000, 6, 64, 2, 0, True, None),          # rocFFT Doppler path
 ])
-def test_caf_multi_equals_single_calls_and_oracle(n, R, F, nref, caf, win, n_in):
+@pytest.mark.parametrize("mode", ["turns", "shared"])
+def test_caf_multi_equals_single_calls_and_oracle(n, R, F, nref, caf, win, n_in, mode, monkeypatch):
     """prc_caf_execute_multi (every reference channel against ONE surveillance channel in one call) returns what one
     fast_xambg per pair returns (range_doppler_processing.py:81-89) -- and what the oracle computes"""
     from passiveradar_amd import range_doppler_processing as rdp
+    # both ways prc_caf_execute_multi can run: one pass per illuminator, or the surveillance transforms shared
+    monkeypatch.setenv("PRC_CAF_MULTI_MODE", {"turns": "0", "shared": "1"}[mode])
     m = n if n_in is None else n_in
     refs, srv = scene.make_multi_scene(m, 1e5, min(R, 200), [7000 + 13 * i + n + R for i in range(nref)])
     w = np.kaiser(n, 5.0) if win else None
@@ -751,12 +754,14 @@ def test_caf_multi_batched_overlapped_frames_and_errors():
     assert rel_err(dd[1].cpu().numpy(), O.fast_xambg(refs[1][:n], srv[:n], R, F)) < TIGHT
 
 
-def test_caf_cfg5_digest_multi():
+@pytest.mark.parametrize("mode", ["turns", "shared"])
+def test_caf_cfg5_digest_multi(mode, monkeypatch):
     """BASELINE config 5 at full size (N = 2^23, 2048 x 2048, four illuminators against one surveillance channel)
     against digests of the REFERENCE's own fast_xambg, one per illuminator (oracle/gen_golden.py
     caf_cfg5_digest_case); the multi call, which shares the surveillance transforms"""
     from scipy.signal import get_window
     from passiveradar_amd.range_doppler_processing import fast_xambg_multi
+    monkeypatch.setenv("PRC_CAF_MULTI_MODE", {"turns": "0", "shared": "1"}[mode])
     g = load_golden("caf_cfg5_digest")
     n, R, F = int(g["N"]), int(g["R"]), int(g["F"])
     refs, srv = scene.make_multi_scene(n, float(g["fs"]), R, [int(sd) for sd in g["seeds"]])
