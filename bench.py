@@ -129,7 +129,7 @@ def _cpu_frame_worker(args):
 
 
 def cpu_baseline(workload, max_workers=32, asis=False):
-    """(i) one core, bounded sample; (ii) all cores: one frame per worker process on min(cores, 32) workers."""
+    """(i) one core, bounded sample; (ii) one frame per worker process on min(cores, max_workers) workers."""
     import multiprocessing as mp
     fs, n, R, F, clutter, _ = WORKLOADS[workload]
     cores = os.cpu_count() or 1
@@ -162,6 +162,22 @@ def cpu_baseline(workload, max_workers=32, asis=False):
     }
 
 
+def fm_suppression(L=64):
+    """SURVEY 8d's report-only figure: clutter suppression (dB) of the five-bin LS chain on an FM-like illuminator
+    (badly conditioned Toeplitz system), device vs the oracle's per-bin complex128 Levinson (CPU, test infrastructure)."""
+    from oracle import np_oracle as O
+    from passiveradar_amd import scene
+    from passiveradar_amd.clutter_removal import LS_Filter_Multiple
+    n, fs = 262144, 262184.87
+    ref, srv = scene.make_fm_scene(n, fs, L, 2024)
+    bins = [0, 1, -1, 2, -2]
+    core = slice(2 * L, n - 2 * L)
+    p_in = np.mean(np.abs(srv[core]) ** 2)
+    sup = lambda y: float(10 * np.log10(p_in / np.mean(np.abs(y[core]) ** 2)))
+    return {"device": sup(LS_Filter_Multiple(ref, srv, L, fs, bins)), "oracle": sup(O.LS_Filter_Multiple(ref, srv, L, fs, bins)),
+            "scene": f"FM-like reference (75 kHz deviation, 15 kHz audio), N={n}, {L + 10} taps, bins {bins}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +205,9 @@ def main():
                     help="also time the reference CAF as it ships (SciPy's per-lag np.roots call left in) on a few lag "
                          "columns, scaled: the transparency figure of SURVEY 8d")
     ap.add_argument("--no-clutter", action="store_true", help="CAF only (reported as a different metric)")
+    ap.add_argument("--dump", default=None, metavar="NPZ",
+                    help="single GPU: save the maps of the last timed step's first, second, middle and last frame "
+                         "(+ every frame's sum) so a test can hold the benchmarked path against an independent pass")
     args = ap.parse_args()
 
     import torch
@@ -386,6 +405,12 @@ def main():
         rank_seconds = [float(t.item()) for t in every]
         dt = max(rank_seconds)
     value = frames_per_step_total * steps / dt      # a multi-illuminator frame = all its CAF surfaces
+    if args.dump and world == 1 and nframes:
+        last = outs[(stepno[0] - 1) % nsets]
+        pick = sorted({0, min(1, nframes - 1), nframes // 2, nframes - 1})
+        np.savez(args.dump, frame_index=np.array(pick), seed0=seed0, nframes=nframes,
+                 **{f"ill{i}_frames": o[pick].cpu().numpy() for i, o in enumerate(last)},
+                 **{f"ill{i}_sums": o[:nframes].sum(dim=(1, 2)).cpu().numpy() for i, o in enumerate(last)})
 
     # ---- per-kernel timing with HIP events on the launch stream (rank 0) --------------------
     result = None
@@ -528,6 +553,21 @@ def main():
             result["cpu_baseline"] = cb
             result["speedup_vs_cpu_all_cores_measured"] = value / cb["value"]
             result["speedup_vs_cpu_1core"] = value / cb["one_core_value"]
+            if clutter == "ls":
+                result["fm_like_suppression_dB"] = fm_suppression(R if wl == "cfg1" else 64)
+            if args.cpu_asis:
+                # the reference as it ships: scipy.signal.decimate calls dlti._as_zpk -> np.roots on the (q+1)-tap
+                # boxcar once per lag column (no effect on the result; bypassed in every other figure of this line)
+                q = n // F
+                t0 = time.perf_counter()
+                np.roots(np.ones(q + 1))
+                t_roots = time.perf_counter() - t0
+                per_frame = nill * ((R + 1) * t_roots + cb["one_core_caf_seconds"]) + cb["one_core_clutter_seconds"]
+                result["cpu_reference_as_is"] = {
+                    "np_roots_seconds_per_lag": t_roots, "lags": R + 1, "seconds_per_frame": per_frame,
+                    "frames_per_s": 1.0 / per_frame,
+                    "note": f"one np.roots(ones({q + 1})) timed on this box (LAPACK may use several cores), times the "
+                            f"{R + 1} lag columns, plus the one-core path above"}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -132,7 +132,11 @@ typedef struct prc_ls_desc {
                               recompute the reference spectra per Doppler bin, 3 FFT kernels with
                               the reference spectra cached in HBM between Doppler bins.  The FFT
                               kernels take up to 769 taps on 1024-point transforms (one wavefront
-                              each) and up to 3073 taps on 4096-point transforms (four wavefronts) */
+                              each) and up to 3073 taps on 4096-point transforms (four wavefronts).
+                              LIMIT: filter_len + peek <= 3413 taps for every method (the Levinson
+                              recursion keeps three T-vectors of complex128 in the 160 KB of LDS);
+                              beyond that prc_ls_plan_create returns PRC_EUNSUPPORTED -- the reference
+                              (clutter_removal.py:109-160) accepts any length                         */
 } prc_ls_desc;
 
 typedef struct prc_ls_plan prc_ls_plan;
@@ -160,7 +164,9 @@ int prc_ls_set_profiling(prc_ls_plan* plan, int32_t enable);
 int prc_ls_get_profile(prc_ls_plan* plan, double* ms, int32_t* launches_per_kind);
 
 /* ---- NLMS_filter (clutter_removal.py:189-249) ---------------------------------------- */
-/* nstreams independent sample-recursive filters, one wavefront each.  taps_in: optional
+/* LIMIT: filter_len + peek <= 2048 taps (a stream's taps live in the registers of one wavefront, 32 per lane);
+ * beyond that PRC_EUNSUPPORTED -- the reference (clutter_removal.py:189-249) accepts any length.
+ * nstreams independent sample-recursive filters, one wavefront each.  taps_in: optional
  * complex64 [nstreams][T] initial taps (initialTaps), NULL = zeros.  taps_out: optional
  * complex64 [nstreams][T].  out: complex64, zero outside [filter_len, n-peek). */
 int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int64_t stride,
@@ -256,6 +262,7 @@ int prc_channel_offset(const void* s1, int64_t n1, const void* s2, int64_t n2, c
 typedef struct prc_comm prc_comm;
 int prc_comm_unique_id(void* id_host);                       /* HOST buffer of PRC_COMM_ID_BYTES      */
 int prc_comm_create(prc_comm** comm, const void* id_host, int32_t rank, int32_t world);
+int prc_comm_rccl_version(int32_t* version);                  /* ncclGetVersion of the RCCL that was bound      */
 int prc_comm_destroy(prc_comm* comm);
 /* send: this rank's frames_per_rank_host[rank] frames of frame_elems complex64 (DEVICE).  recv (root
  * only, DEVICE): sum(frames_per_rank_host) frames, rank r's block at frame offset sum_{q<r}.  Blocks may

@@ -109,6 +109,7 @@ _SIGNATURES = {
     "prc_comm_unique_id": (C.c_int, [C.c_void_p]),
     "prc_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_int32]),
     "prc_comm_destroy": (C.c_int, [C.c_void_p]),
+    "prc_comm_rccl_version": (C.c_int, [C.POINTER(C.c_int32)]),
     "prc_gather_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_void_p,
                                     C.c_int32, C.c_void_p]),
 }
@@ -185,6 +186,12 @@ def current_device():
     """the calling thread's current HIP device index (-1 without a GPU)"""
     d = C.c_int(-1)
     return d.value if lib().prc_get_device(C.byref(d)) == PRC_OK else -1
+
+
+def rccl_version():
+    """ncclGetVersion of the RCCL bound by the gather (None when RCCL cannot be loaded)"""
+    v = C.c_int32(0)
+    return int(v.value) if lib().prc_comm_rccl_version(C.byref(v)) == PRC_OK else None
 
 
 def require_gpu():

@@ -89,10 +89,19 @@ extern "C" int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int3
     for (Scratch& c : pool)
         if (c.dev == dev && c.stream == stream) { hit = &c; break; }
     if (!hit) {
-        if (pool.size() >= 16) {                      // a host cycling through many streams: start over
+        // a host cycling through many streams: once THIS device holds 16 blocks, drop this device's blocks (after
+        // synchronising it -- hipDeviceSynchronize covers the current device only, so blocks on other devices, whose
+        // kernels may still be queued, are left alone)
+        size_t mine = 0;
+        for (const Scratch& c : pool) mine += c.dev == dev;
+        if (mine >= 16) {
             PRC_HIP(hipDeviceSynchronize());
-            for (Scratch& c : pool) (void)hipFree(c.p);
-            pool.clear();
+            std::vector<Scratch> keep;
+            for (Scratch& c : pool) {
+                if (c.dev == dev) (void)hipFree(c.p);
+                else keep.push_back(c);
+            }
+            pool.swap(keep);
         }
         pool.push_back(Scratch());
         hit = &pool.back();

@@ -32,6 +32,7 @@ struct RcclApi {
     nccl_result_t (*Send)(const void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     nccl_result_t (*Recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(nccl_result_t) = nullptr;
+    nccl_result_t (*GetVersion)(int*) = nullptr;
 };
 
 RcclApi g_rccl;
@@ -60,6 +61,7 @@ int rccl_load() {
     PRC_RCCL_SYM(Send, "ncclSend");
     PRC_RCCL_SYM(Recv, "ncclRecv");
     PRC_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+    PRC_RCCL_SYM(GetVersion, "ncclGetVersion");
 #undef PRC_RCCL_SYM
     g_rccl = api;
     return PRC_OK;
@@ -92,6 +94,16 @@ extern "C" int prc_comm_unique_id(void* id_host) {
     return PRC_OK;
 }
 
+extern "C" int prc_comm_rccl_version(int32_t* version) {
+    PRC_REQUIRE(version, PRC_EINVAL, "prc_comm_rccl_version: null argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    int v = 0;
+    PRC_RCCL(g_rccl.GetVersion(&v));
+    *version = v;
+    return PRC_OK;
+}
+
 extern "C" int prc_comm_create(prc_comm** comm, const void* id_host, int32_t rank, int32_t world) {
     PRC_REQUIRE(comm && id_host, PRC_EINVAL, "prc_comm_create: null argument");
     PRC_REQUIRE(world >= 1 && rank >= 0 && rank < world, PRC_EINVAL,
@@ -120,6 +132,21 @@ extern "C" int prc_comm_destroy(prc_comm* c) {
     return PRC_OK;
 }
 
+// RCCL usage, checked against its rules for point-to-point operations:
+//  * a peer issues ONE ncclSend per gather (no group needed for a single operation); the root issues one ncclRecv per
+//    peer inside ncclGroupStart/End, so the receives are posted together and progress concurrently -- a root that posted
+//    them one by one outside a group would serialise the peers in rank order;
+//  * send/recv pairs between two ranks match in issue order on the same communicator: every rank calls
+//    prc_gather_frames the same number of times in the same order (bench.py and StreamProcessor do), so the k-th send of
+//    peer r meets the k-th receive group of the root; counts and types agree by construction (the same
+//    frames_per_rank_host array on every rank);
+//  * all operations of one communicator are enqueued on ONE stream per rank, by one thread at a time (c->mtx), so
+//    they execute in issue order; the caller orders that stream after the kernels that produce `send` and before the
+//    consumers of `recv` with events;
+//  * a second communicator in the process (torch.distributed's own RCCL communicator) is only ever used while no
+//    gather of this one is in flight: bench.py drains its pending gathers before every barrier / all-reduce, so two
+//    communicators never have blocking kernels queued in different orders on different ranks (the cross-communicator
+//    deadlock RCCL warns about).
 extern "C" int prc_gather_frames(prc_comm* c, const void* send, const int64_t* frames_per_rank_host,
                                  int64_t frame_elems, void* recv, int32_t root, void* stream_) {
     PRC_REQUIRE(c && frames_per_rank_host, PRC_EINVAL, "prc_gather_frames: null argument");

@@ -193,19 +193,23 @@ __device__ __forceinline__ double wave_allsum_d(double v) {
     return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
-// LDS: c[T], bb[T], a0[T], a1[T], w[T] (double2).  Same recursion as levinson_kernel.
+// LDS: c[T], a[T], w[T] (double2) -- 48 T bytes, so filters up to 3413 taps fit the 160 KB of a CU (the 4096-point FFT
+// kernels carry 3073).  Same recursion as levinson_kernel with the predictor updated IN PLACE: step m turns a[j] and
+// a[m-j] into a[j] + k conj(a[m-j]) and a[m-j] + k conj(a[j]) together, one lane per pair, so no second predictor
+// buffer exists and a lane's loop is half as long; the right-hand side b is read from HBM one element per step
+// (round 2 held five arrays in LDS and stopped at 2047 taps).
 __global__ __launch_bounds__(64) void levinson_wave_kernel(const float2* __restrict__ partial,
                                                            int nblk, int T, double reg,
-                                                           double2* __restrict__ taps_out) {
+                                                           double2* __restrict__ taps_out,
+                                                           double2* __restrict__ rhs_ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double2* c = reinterpret_cast<double2*>(smem_raw);
-    double2* bb = c + T;
-    double2* abuf0 = bb + T;
-    double2* abuf1 = abuf0 + T;
-    double2* w = abuf1 + T;
+    double2* a = c + T;
+    double2* w = a + T;
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const float2* part = partial + (int64_t)b * nblk * 2 * T;
+    double2* __restrict__ bb = rhs_ws + (int64_t)b * T;
     for (int k = lane; k < T; k += 64) {
         double cr = 0, ci = 0, br = 0, bi = 0;
 #pragma unroll 4
@@ -218,21 +222,19 @@ __global__ __launch_bounds__(64) void levinson_wave_kernel(const float2* __restr
         if (k == 0) cr += reg;
         c[k] = make_double2(cr, -ci);
         bb[k] = make_double2(br, -bi);
-        abuf0[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
-        abuf1[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
+        a[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
         w[k] = make_double2(0.0, 0.0);
     }
-    __syncthreads();
+    __syncthreads();                              // one wavefront: orders the LDS and the global writes above
     double err = c[0].x;
     if (lane == 0) w[0] = zdiv(bb[0], c[0]);
     __syncthreads();
-    double2* a_old = abuf0;
-    double2* a_new = abuf1;
     for (int m = 1; m < T; ++m) {
+        const double2 bm = bb[m];                  // issued before the reductions: its latency sits under them
         double2 acc = make_double2(0, 0), dot = make_double2(0, 0);
         for (int i = lane; i < m; i += 64) {
             const double2 cm = c[m - i];
-            acc = zadd(acc, zmul(a_old[i], cm));
+            acc = zadd(acc, zmul(a[i], cm));
             dot = zadd(dot, zmul(cm, w[i]));
         }
         acc.x = wave_allsum_d(acc.x);
@@ -242,20 +244,24 @@ __global__ __launch_bounds__(64) void levinson_wave_kernel(const float2* __restr
         const double rerr = 1.0 / err;
         const double2 k = make_double2(-acc.x * rerr, -acc.y * rerr);
         err = err * (1.0 - (k.x * k.x + k.y * k.y));
-        const double2 res = zsub(bb[m], dot);
+        const double2 res = zsub(bm, dot);
         const double rerr2 = 1.0 / err;
         const double2 g = make_double2(res.x * rerr2, res.y * rerr2);
-        for (int j = lane; j <= m; j += 64) {
-            const double2 aj = a_old[j];
-            const double2 amj = a_old[m - j];
-            a_new[j] = zadd(aj, zmul(k, zconj(amj)));
-            const double2 anew_mj = zadd(amj, zmul(k, zconj(aj)));
-            w[j] = zadd(w[j], zmul(g, zconj(anew_mj)));
+        __builtin_amdgcn_wave_barrier();           // every lane has read a[] and w[] for the sums
+        for (int j = lane; 2 * j <= m; j += 64) {
+            const int mj = m - j;
+            const double2 aj = a[j];
+            const double2 amj = a[mj];
+            const double2 nj = zadd(aj, zmul(k, zconj(amj)));
+            const double2 nmj = zadd(amj, zmul(k, zconj(aj)));
+            a[j] = nj;
+            w[j] = zadd(w[j], zmul(g, zconj(nmj)));
+            if (mj != j) {
+                a[mj] = nmj;
+                w[mj] = zadd(w[mj], zmul(g, zconj(nj)));
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        double2* t = a_old;
-        a_old = a_new;
-        a_new = t;
     }
     for (int k = lane; k < T; k += 64) taps_out[(int64_t)b * T + k] = w[k];
 }
@@ -812,6 +818,7 @@ struct prc_ls_plan {
     bool team = false; // 770 .. 3073 taps: the 4096-point team kernels of ls_fft_team.hip
     float2* d_partial = nullptr;
     double2* d_taps = nullptr;
+    double2* d_rhs = nullptr;      // right-hand sides of the per-bin Levinson solve, [block][T] (one element read per step)
     float2* d_tmp[2] = {nullptr, nullptr};
     // shared-inverse path (non-circular FFT chain): c_0, S_e, dense T_0^{-1} per block
     double2* d_c0 = nullptr;
@@ -836,6 +843,7 @@ extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
     if (!p) return PRC_OK;
     if (p->d_partial) (void)hipFree(p->d_partial);
     if (p->d_taps) (void)hipFree(p->d_taps);
+    if (p->d_rhs) (void)hipFree(p->d_rhs);
     if (p->d_tmp[0]) (void)hipFree(p->d_tmp[0]);
     if (p->d_tmp[1]) (void)hipFree(p->d_tmp[1]);
     if (p->d_c0) (void)hipFree(p->d_c0);
@@ -850,7 +858,7 @@ extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
     return PRC_OK;
 }
 
-static size_t levinson_lds(int T) { return sizeof(double2) * ((size_t)5 * T); }
+static size_t levinson_lds(int T) { return sizeof(double2) * ((size_t)3 * T); }
 static size_t fir_lds(int T) { return sizeof(float2) * ((size_t)T + FIR_SPAN + T - 1); }
 
 extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
@@ -862,7 +870,7 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     PRC_REQUIRE(T < d->n, PRC_EINVAL, "prc_ls_plan_create: filter_len+peek (%d) >= n (%lld)", T,
                 (long long)d->n);
     PRC_REQUIRE(levinson_lds(T) <= 160 * 1024, PRC_EUNSUPPORTED,
-                "prc_ls_plan_create: %d taps exceed the LDS-resident Levinson solver (max 2047)", T);
+                "prc_ls_plan_create: %d taps exceed the LDS-resident Levinson solver (max 3413)", T);
     prc_ls_plan* p = new prc_ls_plan();
     p->desc = *d;
     p->T = T;
@@ -881,6 +889,7 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     p->nblk = p->method == 2 ? p->fft_waves : (int)ceil_div64(d->n, LSC_BLK);
     hipError_t e = hipMalloc(&p->d_partial, sizeof(float2) * (size_t)d->max_blocks * p->nblk * 2 * T);
     if (e == hipSuccess) e = hipMalloc(&p->d_taps, sizeof(double2) * (size_t)d->max_blocks * T);
+    if (e == hipSuccess) e = hipMalloc(&p->d_rhs, sizeof(double2) * (size_t)d->max_blocks * T);
     if (e == hipSuccess) e = hipMalloc(&p->d_tmp[0], sizeof(float2) * (size_t)d->max_blocks * d->n);
     if (e == hipSuccess) e = hipMalloc(&p->d_tmp[1], sizeof(float2) * (size_t)d->max_blocks * d->n);
     if (e == hipSuccess && p->method == 2 && !d->circular && !p->team) {
@@ -1140,7 +1149,7 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
             if (rc) return rc;
             if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 1], stream));
             hipLaunchKernelGGL(levinson_wave_kernel, dim3(nblocks), dim3(64), levinson_lds(T), stream,
-                               p->d_partial, p->nblk, T, reg, p->d_taps);
+                               p->d_partial, p->nblk, T, reg, p->d_taps, p->d_rhs);
             PRC_LAUNCH_CHECK();
             if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
             if (p->method == 2) {

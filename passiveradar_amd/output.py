@@ -50,6 +50,11 @@ def _hdf5_lib():
             h = C.CDLL(c)
             if h.H5open() < 0:
                 continue
+            # hid_t is 64 bits wide from HDF5 1.10 on (32 bits in 1.8.x, where the signatures below would pass garbage
+            # handles): older libraries are refused rather than bound
+            maj, mnr, rel = C.c_uint(), C.c_uint(), C.c_uint()
+            if h.H5get_libversion(C.byref(maj), C.byref(mnr), C.byref(rel)) < 0 or (maj.value, mnr.value) < (1, 10):
+                continue
         except (OSError, AttributeError):
             continue
         hid, hsz, pp = C.c_int64, C.c_uint64, C.POINTER(C.c_uint64)

@@ -38,7 +38,7 @@ def worker(wseed):
           w = None if rng.random() < 0.5 else np.kaiser(N, 4.0)
           note("caf_wide", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("cafwide", N, R, F, w is not None))
       elif k == 16:   # long LS filters on the 4096-point team kernels (770 .. 3073 taps), linear and circular
-          L = int(rng.choice([760, 790, 1024, 1500, 2047 - 10])); N = int(rng.integers(3 * L, 60000))
+          L = int(rng.choice([760, 790, 1024, 1500, 2047 - 10, 3063])); N = int(rng.integers(3 * L, 60000))
           ref, srv = scene.make_scene(N, 1e6, 100, int(rng.integers(1 << 30)))
           if rng.random() < 0.7:
               bins = [0.0, 2.0, -1.0][:int(rng.integers(1, 4))]

@@ -1,0 +1,86 @@
+"""prc_gather_frames between REAL ranks: two (or more) processes, one GPU each, RCCL through the C ABI.
+
+Skipped on a box with fewer than two GPUs (the driver's GPU test box has one); on a multi-GPU node it is the
+only test that runs the multi-rank branch of passiveradar_amd/csrc/gather.hip (ncclSend on the peers, the grouped
+ncclRecv set on the root): ragged and empty blocks, a root other than rank 0, a FrameComm over a torch sub-group whose
+ranks differ from the global ones, and the sharded stream driver end to end against the unsharded pass."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from passiveradar_amd import scene
+    from passiveradar_amd.stream import FrameComm, HipBackend, Shard, StreamProcessor, gather_frames, shard_sizes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        comm = FrameComm.from_torch_distributed()
+        F, cols = 8, 5
+        # ragged blocks (ceil split of 2 * world + 1 frames), root 0 and root world - 1
+        total = 2 * world + 1
+        per = -(-total // world)
+        lo, hi = min(rank * per, total), min((rank + 1) * per, total)
+        sh = Shard(rank, world, total, lo, hi, lo, hi)
+        mine = torch.full((hi - lo, F, cols), float(rank + 1), dtype=torch.complex64, device=dev)
+        mine += torch.arange(lo, hi, device=dev, dtype=torch.float32).reshape(-1, 1, 1) * 1j
+        for root in (0, world - 1):
+            res = gather_frames(mine, sh, dst=root, comm=comm)
+            if rank == root:
+                sizes = shard_sizes(sh)
+                exp = torch.cat([torch.full((m, F, cols), float(r + 1), dtype=torch.complex64) for r, m in enumerate(sizes)])
+                exp += torch.arange(total, dtype=torch.float32).reshape(-1, 1, 1) * 1j
+                assert torch.equal(res.cpu(), exp), f"root {root}"
+            else:
+                assert res is None
+        # the sharded stream driver against the unsharded pass on rank 0
+        C, R, Fd, fs = 16384, 24, 64, 1.0e5
+        ref, srv = scene.make_stream(3 * world + 1, C, fs, R, 2026)
+        be = HipBackend(2 * C, R, Fd, fs, batch=8, device=dev)
+        full = StreamProcessor(be, rank, world, comm=comm).process(ref, srv)
+        if rank == 0:
+            one = StreamProcessor(HipBackend(2 * C, R, Fd, fs, batch=8, device=dev)).process(ref, srv)
+            err = float((full - one).abs().max() / one.abs().max())
+            assert err < 1e-6, err
+        comm.close()
+        q.put((rank, "ok"))
+    except Exception as e:                      # noqa: BLE001 -- reported to the parent, which fails the test
+        q.put((rank, repr(e)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_prc_gather_frames_between_ranks(gpu_ready):
+    import torch
+    import torch.multiprocessing as mp
+    world = min(torch.cuda.device_count(), 4)
+    if world < 2:
+        pytest.skip("needs at least two GPUs: the multi-rank RCCL branch of prc_gather_frames")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=600)
+    assert all(msg == "ok" for _, msg in got), got
+    assert all(p.exitcode == 0 for p in procs)

@@ -300,3 +300,46 @@ def test_bench_workload_modes_run(args, frames):
     assert d["scaling"] == ("strong" if "cfg4" in args else "weak")
     assert d["roofline"]["bound"] in ("hbm", "valu") and 0 < d["roofline"]["frac"] < 1.5
     assert abs(d["value"] - frames * d["steps"] / d["timed_seconds"]) / d["value"] < 1e-6
+
+
+def test_bench_cfg4_maps_against_an_independent_pass(tmp_path):
+    """what bench.py --workload cfg4 computes IS the stream pipeline: its maps (dumped from the last timed step of a
+    21-frame stream at full config-2 frame size) equal an independent pass over the regenerated stream -- other
+    sub-batch size, LS and CAF back to back on one stream -- and one frame equals the CPU oracle end to end"""
+    import subprocess
+    import sys
+    import torch
+    from scipy.signal import get_window
+    from oracle import np_oracle as O
+    from passiveradar_amd.stream import HipBackend
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    dump = str(tmp_path / "cfg4.npz")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--no-cpu", "--steps", "2", "--warmup", "1",
+                        "--workload", "cfg4", "--frames", "21", "--dump", dump],
+                       capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = np.load(dump)
+    fs, n, R, F, _, _ = bench.WORKLOADS["cfg4"]
+    C, nfr = n // 2, int(d["nframes"])
+    assert nfr == 21
+    # the stream as bench.py builds it in strong-scaling mode: 64-chunk segments keyed by the global chunk index
+    a, s_ = bench.synth_segment(torch, 64, C, fs, R, int(d["seed0"]) * 1000003 + 0, torch.device("cuda", 0), t0=0.0)
+    ref, srv = a[:nfr * C], s_[:nfr * C]
+    be = HipBackend(n, R, F, fs, batch=5, overlap=False)
+    maps = be.run(be.padded(ref), be.padded(srv), nfr, 0, nfr)
+    torch.cuda.synchronize()
+    got = d["ill0_frames"]
+    for j, fi in enumerate(d["frame_index"]):
+        assert rel_err(got[j], maps[int(fi)].cpu().numpy()) < 1e-6, int(fi)
+    assert rel_err(d["ill0_sums"], maps.sum(dim=(1, 2)).cpu().numpy()) < 1e-5
+    # one frame end to end on the CPU: LS_Filter_Multiple on its three chunks, overlapped CPI, fast_xambg
+    fi = 1
+    rh, sh = ref[:3 * C].cpu().numpy(), srv[:3 * C].cpu().numpy()
+    clean = np.concatenate([O.LS_Filter_Multiple(rh[i * C:(i + 1) * C], sh[i * C:(i + 1) * C], R, fs, [0, 1, -1, 2, -2])
+                            for i in range(3)]).astype(np.complex64)
+    pad = np.zeros(C // 2, np.complex64)
+    rp, cp = np.concatenate((pad, rh, pad)), np.concatenate((pad, clean, pad))
+    exp = O.fast_xambg(rp[fi * C:fi * C + n], cp[fi * C:fi * C + n], R, F, n, get_window(("kaiser", 5.0), n))[:, :, 0]
+    assert rel_err(got[list(d["frame_index"]).index(fi)], exp) < 1e-4

@@ -190,6 +190,26 @@ def test_hdf5_output_through_libhdf5(tmp_path):
     assert raw.find(want.tobytes()) > 0                       # contiguous layout: the C-order array sits in the file as is
     with pytest.raises(KeyError):
         output.load_range_doppler_hdf5(p, "/nothing")
+    # an outside reader: the HDF5 project's own h5dump (what range_doppler_plot.py:43-47 would meet through h5py):
+    # dataset path, shape (F, R+1, nframes), the compound {r, i} of little-endian float32 h5py stores complex64 as,
+    # and the numbers of one frame
+    import re
+    import shutil
+    import subprocess
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if os.path.exists("/opt/conda/bin/h5dump") else None)
+    if h5dump is None:
+        pytest.skip("no h5dump on this machine (the library round trip above passed)")
+    hdr = subprocess.run([h5dump, "-H", p], capture_output=True, text=True, check=True).stdout
+    assert re.search(r'DATASET "xambg"', hdr)
+    assert re.search(r'H5T_COMPOUND\s*\{\s*H5T_IEEE_F32LE "r";\s*H5T_IEEE_F32LE "i";\s*\}', hdr)
+    assert re.search(r"DATASPACE\s+SIMPLE\s*\{\s*\(\s*6,\s*5,\s*4\s*\)", hdr)
+    txt = subprocess.run([h5dump, "-d", "/xambg", "-s", "0,0,2", "-c", "6,5,1", "-m", "%.9g", p],
+                         capture_output=True, text=True, check=True).stdout
+    cells = re.findall(r"\((\d+),(\d+),(\d+)\):\s*\{\s*([-+0-9.eE]+),\s*([-+0-9.eE]+)\s*\}", txt)
+    assert len(cells) == 30
+    for f_, k_, i_, re_, im_ in cells:
+        v = frames[int(i_), int(f_), int(k_)]
+        assert int(i_) == 2 and np.float32(re_) == v.real and np.float32(im_) == v.imag
 
 
 def test_iir_decimator_design_matches_scipy():
