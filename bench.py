@@ -55,7 +55,8 @@ WORKLOADS = {
     # config 4: 600 s of cfg-2 IQ, hop 0.5 s -> 1200 chunks, trimmed by one (main.py:116-120) -> 1199 frames
     "cfg4": (2.4e6, 2400000, 256, 512, "ls", 1199),
     # config 5: 20 MS/s, 2048 x 2048, four illuminators against one surveillance channel, CAF only
-    "cfg5": (2.0e7, 1 << 23, 2048, 2048, None, 8),
+    # (16 frames = 64 surfaces per step: with 8 the segment kernel's last wave of workgroups is a visible tail)
+    "cfg5": (2.0e7, 1 << 23, 2048, 2048, None, 16),
 }
 N_ILLUMINATORS = {"cfg5": 4}
 SUB_BATCH = 256                # frames per CAF launch, per LS launch and per gather

@@ -1,0 +1,49 @@
+#!/bin/bash
+# One round's evidence in one gpurun call (run from the repo root on the GPU box):   tools/evidence.sh r03
+# Everything lands under gpurun_out/ev_<tag>/ as raw rocprofv3 CSVs + the exact command of every run (cmd.txt), and
+# tools/evidence_summarize.py (run at the end, on the box) writes the summaries that get copied into profiles/.
+# rocprofv3 rules of this pool: counters (--pmc) in their own passes, never together with a trace domain.
+tag=${1:-r03}
+R=${GRAFT_REPO_ROOT:-$PWD}
+E=$R/gpurun_out/ev_$tag
+mkdir -p $E
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py"
+run() {   # run <name> <command...>: stdout+stderr to <name>.log, the JSON line (if any) to <name>.json
+  local name=$1; shift
+  echo "$*" > $E/$name.cmd.txt
+  "$@" > $E/$name.log 2>&1
+  grep '^{' $E/$name.log | tail -1 > $E/$name.json
+}
+trace() { # trace <name> <bench args...>
+  local name=$1; shift
+  echo "rocprofv3 --kernel-trace --stats -- python bench.py $*" > $E/$name.cmd.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $E/$name -o t -- $B "$@" > $E/$name.log 2>&1
+  grep '^{' $E/$name.log | tail -1 > $E/$name.json
+}
+pmc() {   # pmc <name> <bench args...>: one pass per counter group
+  local name=$1; shift
+  echo "rocprofv3 --pmc <group> -- python bench.py $*   (one pass per group: FETCH_SIZE | WRITE_SIZE | SQ groups)" > $E/$name.cmd.txt
+  local i=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" \
+             "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+    i=$((i+1))
+    rocprofv3 --pmc $grp --output-format csv -d $E/$name/g$i -o pmc -- $B "$@" > $E/$name.g$i.log 2>&1
+  done
+  grep '^{' $E/$name.g1.log | tail -1 > $E/$name.json
+}
+# 1. the bench lines of record (default with the CPU leg and the as-is figure; the other configs with their CPU legs)
+run bench_default $B --cpu-asis
+run bench_cfg3 $B --workload cfg3
+run bench_cfg4 $B --workload cfg4 --no-cpu
+run bench_cfg5 $B --workload cfg5
+# 2. kernel traces: the default pipeline (overlapped streams) and the same kernels back to back on one stream
+trace trace_cfg2 --no-cpu --frames 1024 --steps 5 --warmup 1
+trace trace_cfg2_serial --no-cpu --frames 1024 --steps 5 --warmup 1 --no-overlap
+trace trace_cfg3 --no-cpu --workload cfg3 --frames 512 --steps 1 --warmup 1
+trace trace_cfg5 --no-cpu --workload cfg5 --steps 20 --warmup 2
+# 3. counters
+pmc pmc_cfg2 --no-cpu --frames 256 --steps 2 --warmup 1 --no-overlap
+pmc pmc_cfg3 --no-cpu --workload cfg3 --no-clutter --frames 64 --steps 2 --warmup 1
+pmc pmc_cfg5 --no-cpu --workload cfg5 --steps 2 --warmup 1
+python3 $R/tools/evidence_summarize.py $tag
