@@ -51,8 +51,11 @@ for name in ("trace_cfg2", "trace_cfg2_serial", "trace_cfg3", "trace_cfg5"):
         f.write(f"Workload of THIS run (from its own JSON line): {cfg['workload']}; {cfg['frames_per_gpu_per_step']} frames per step, "
                 f"{line['steps']} timed steps, {line['value']:.0f} frames/s under the profiler.\n\n")
         f.write("| kernel | calls | avg us / launch | % of GPU time |\n|---|---|---|---|\n")
-        for r in rows[:14]:
+        ours = [r for r in rows if short(r["Name"]).startswith(OURS) or "rocfft" in r["Name"].lower()]
+        other = sum(float(r["Percentage"]) for r in rows) - sum(float(r["Percentage"]) for r in ours)
+        for r in ours[:16]:
             f.write(f"| `{short(r['Name'])[:64]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} |\n")
+        f.write(f"| (torch kernels that generate the synthetic IQ before the timed region, fills, copies) | | | {other:.2f} |\n")
         f.write("\nbench.py's own HIP-event timings in the same process (each kernel alone on its stream; `units` = frames or hop chunks behind one launch):\n\n"
                 "| bench name | avg ms / launch | launches / step | algorithmic GB/s or TFLOP/s |\n|---|---|---|---|\n")
         for k, v in line["kernels"].items():
