@@ -197,6 +197,9 @@ def main():
     ap.add_argument("--gather", default="auto", choices=["auto", "prc", "torch", "none"],
                     help="N>1: prc = prc_gather_frames (RCCL through the C ABI), torch = torch.distributed.gather, "
                          "auto = prc when every rank could create the communicator, else torch")
+    ap.add_argument("--gather-parts", type=int, default=4,
+                    help="cfg4, N>1: gather a shard's maps in this many rounds, each as soon as its frames are done "
+                         "(1 = one gather after the whole shard)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-multi", action="store_true",
                     help="cfg5: one fast_xambg pass per illuminator instead of the shared-surveillance multi call")
@@ -206,6 +209,9 @@ def main():
                     help="also time the reference CAF as it ships (SciPy's per-lag np.roots call left in) on a few lag "
                          "columns, scaled: the transparency figure of SURVEY 8d")
     ap.add_argument("--no-clutter", action="store_true", help="CAF only (reported as a different metric)")
+    ap.add_argument("--shard-of", default=None, metavar="RANK/WORLD",
+                    help="cfg4 on ONE GPU: process only the shard rank RANK of WORLD would own (its frames + the two halo "
+                         "chunks), no gather -- what one rank of an N-GPU run computes, measurable on a 1-GPU box")
     ap.add_argument("--dump", default=None, metavar="NPZ",
                     help="single GPU: save the maps of the last timed step's first, second, middle and last frame "
                          "(+ every frame's sum) so a test can hold the benchmarked path against an independent pass")
@@ -242,10 +248,14 @@ def main():
     my_ills = [i for i in range(nill) if i % ill_ways == rank % ill_ways]
     if strong:
         total = args.frames or B_default                      # frames in the whole stream
-        shard = prstream.plan_shard(total, rank, world)
+        if args.shard_of and world == 1:
+            fr, fw = (int(v) for v in args.shard_of.split("/"))
+            shard = prstream.plan_shard(total, fr, fw)
+        else:
+            shard = prstream.plan_shard(total, rank, world)
         nlocal, nframes, first = shard.nlocal_chunks, shard.nframes, shard.frame_offset(shard.frame_lo, C)
         B = nframes
-        frames_per_step_total = total
+        frames_per_step_total = total if not (args.shard_of and world == 1) else nframes
     else:
         B = args.frames or B_default
         if nill > 1:
@@ -335,11 +345,17 @@ def main():
         block.record_stream(s_comm)
         pending[k] = (block, work)
 
+    part_work, part_last = [], {}
+    part_gather = (prstream.PartGather(gshard, args.gather_parts, comm=comm, stream=s_comm)
+                   if (strong and gather_mode != "none" and args.gather_parts > 1) else None)
+
     def drain():
         for k in (0, 1):
             if pending[k] is not None:
                 pending[k][1].wait()
                 pending[k] = None
+        while part_work:
+            part_work.pop(0).wait()
 
     # map buffers: two sets used alternately when the maps are gathered, so that a step never overwrites frames a
     # gather of the previous step may still be reading
@@ -354,6 +370,30 @@ def main():
         stepno[0] += 1
         if gathered[p] is not None:
             torch.cuda.current_stream().wait_event(gathered[p])
+        if strong and gather_mode != "none" and args.gather_parts > 1:
+            # the shard's maps leave in rounds while the rest of the shard is still being computed
+            pg = part_gather
+            nxt = [0]
+
+            def on_frames(lo, hi, ev):
+                while nxt[0] < pg.nparts and pg.part_range(nxt[0])[1] <= hi:
+                    a_, b_ = pg.part_range(nxt[0])
+                    s_comm.wait_event(ev)
+                    if comm is None and part_last.get(nxt[0]) is not None:
+                        part_last[nxt[0]].wait()          # torch path: the staging block of this round is free again
+                    with torch.cuda.stream(s_comm):
+                        w_ = pg.gather_part(nxt[0], outs[p][0][a_:b_], recv[p % 2] if rank == 0 else None, async_op=True)
+                    part_work.append(w_)
+                    part_last[nxt[0]] = w_
+                    nxt[0] += 1
+            cuts = [pg.part_range(q)[1] for q in range(pg.nparts)]
+            if nframes:
+                be.run(refs[0], srv_pad, nlocal, first, nframes, out=outs[p][0], cuts=cuts, on_frames=on_frames)
+            on_frames(0, nframes, torch.cuda.current_stream().record_event())      # ranks with empty parts still take part
+            ev_g = torch.cuda.Event()
+            ev_g.record(s_comm)
+            gathered[p] = ev_g
+            return
         if multi and nframes:
             # every illuminator of this rank against the shared surveillance channel in ONE call per sub-batch:
             # prc_caf_execute_multi transforms the surveillance pieces once per segment for all of them

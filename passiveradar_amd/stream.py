@@ -20,7 +20,8 @@ from dataclasses import dataclass
 
 import numpy as np
 
-__all__ = ["Shard", "plan_shard", "shard_sizes", "gather_frames", "FrameComm", "HipBackend", "StreamProcessor"]
+__all__ = ["Shard", "plan_shard", "shard_sizes", "gather_frames", "part_bounds", "PartGather", "FrameComm", "HipBackend",
+           "StreamProcessor"]
 
 
 @dataclass(frozen=True)
@@ -134,17 +135,21 @@ def shard_sizes(shard):
     return [max(min((r + 1) * per, shard.nchunks) - min(r * per, shard.nchunks), 0) for r in range(shard.world)]
 
 
-def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, comm=None, stream=None):
+def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, comm=None, stream=None, counts=None):
     """Gather per-rank frame blocks [m_r][F][R+1] (torch tensors, complex64) to rank ``dst`` -- a rank of ``comm``
     when a FrameComm is given (0 .. comm.world-1; torch.distributed is not touched), else a global
-    torch.distributed rank.  Returns the full [nchunks][F][R+1] tensor on dst, None elsewhere.  ONE collective.
+    torch.distributed rank.  Returns the full [sum m_r][F][R+1] tensor on dst (rank blocks in rank order), None
+    elsewhere.  ONE collective.
+
+    counts: frames sent by every rank (the same list on every rank); default: the contiguous ceil(nchunks/world)
+    split of ``shard`` (plan_shard), i.e. the whole frame-sharded array.
 
     comm: a FrameComm -> prc_gather_frames (RCCL point-to-point group through the C ABI, ragged blocks
     land at their place, nothing is padded); it is enqueued on ``stream`` (a torch stream, default the
     current one).  comm=None -> torch.distributed.gather on ``group`` (gloo in the CPU tests; complex
-    tensors travel as float pairs, blocks padded to ceil(nchunks/world) frames).
+    tensors travel as float pairs, blocks padded to the largest count).
 
-    out: optional preallocated [nchunks][F][R+1] complex64 result on dst -- callers that gather every
+    out: optional preallocated [sum m_r][F][R+1] complex64 result on dst -- callers that gather every
     step pass their own (ping-pong) buffers; by default a fresh tensor is returned, never a cached one.
 
     async_op=True returns ``(result_or_None, work)``: ``work.wait()`` before touching the result (and
@@ -153,63 +158,151 @@ def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, com
     if shard.world == 1:
         return (local, None) if async_op else local
     F, cols = local.shape[1], local.shape[2]
+    counts = shard_sizes(shard) if counts is None else [int(c) for c in counts]
+    if len(counts) != shard.world:
+        raise ValueError(f"gather_frames: {len(counts)} counts for a world of {shard.world}")
+    total = sum(counts)
     if comm is not None:
         # the C-ABI path knows nothing of torch.distributed: ranks, the root and the world are the communicator's own
         # (a FrameComm built over a sub-group, or over any other side channel, numbers its ranks from 0)
         if comm.world != shard.world:
             raise ValueError(f"gather_frames: the communicator has {comm.world} ranks, the shard plan {shard.world}")
-        on_dst = comm.rank == dst
+        me = comm.rank
     else:
         import torch.distributed as dist
-        on_dst = dist.get_rank() == dst                 # global rank, also for sub-groups
+        me = dist.get_rank(group) if group is not None else dist.get_rank()
+        on_dst_global = dist.get_rank() == dst           # dst is a GLOBAL rank on the torch path, also for sub-groups
+    on_dst = (me == dst) if comm is not None else on_dst_global
+    if int(local.shape[0]) != counts[me]:
+        raise ValueError(f"gather_frames: rank {me} holds {int(local.shape[0])} frames, counts say {counts[me]}")
     res = None
     if on_dst:
-        res = out if out is not None else torch.empty((shard.nchunks, F, cols), dtype=torch.complex64,
-                                                       device=local.device)
-        assert tuple(res.shape) == (shard.nchunks, F, cols) and res.is_contiguous()
+        res = out if out is not None else torch.empty((total, F, cols), dtype=torch.complex64, device=local.device)
+        assert tuple(res.shape) == (total, F, cols) and res.is_contiguous()
     if comm is not None:
         import ctypes
         st = torch.cuda.current_stream(local.device) if stream is None else stream
         send = local if local.is_contiguous() else local.contiguous()
         with torch.cuda.device(local.device):
-            comm.gather(send, shard_sizes(shard), F * cols, res, dst, ctypes.c_void_p(st.cuda_stream))
+            comm.gather(send, counts, F * cols, res, dst, ctypes.c_void_p(st.cuda_stream))
         if not async_op:
             st.synchronize()
             return res
         ev = torch.cuda.Event()
         ev.record(st)
         return res, _StreamWork(ev, send)
-    per = -(-shard.nchunks // shard.world)
-    if shard.nframes == per and local.is_contiguous():
+    per = max(counts)
+    if counts[me] == per and local.is_contiguous():
         send = torch.view_as_real(local)
     else:
         send = torch.zeros((per, F, cols, 2), dtype=torch.float32, device=local.device)
-        if shard.nframes:
-            send[:shard.nframes] = torch.view_as_real(local)
+        if counts[me]:
+            send[:counts[me]] = torch.view_as_real(local)
     if on_dst:
         resr = torch.view_as_real(res)
-        recv, tail = [], None
+        recv, tail, lo = [], [], 0
         for r in range(shard.world):
-            lo, hi = r * per, (r + 1) * per
-            if hi <= shard.nchunks:
-                recv.append(resr[lo:hi])                        # lands in place
-            else:                                               # ragged / empty last blocks: staged
+            if counts[r] == per:
+                recv.append(resr[lo:lo + per])                  # lands in place
+            else:                                               # shorter / empty blocks: staged
                 tmp = torch.empty((per, F, cols, 2), dtype=torch.float32, device=local.device)
                 recv.append(tmp)
-                tail = (tail or []) + [(lo, tmp)]
+                tail.append((lo, counts[r], tmp))
+            lo += counts[r]
         work = dist.gather(send, recv, dst=dst, group=group, async_op=async_op)
 
         def finish():
-            for lo, tmp in tail or ():
-                m = max(min(shard.nchunks - lo, per), 0)
+            for lo_, m, tmp in tail:
                 if m:
-                    resr[lo:lo + m].copy_(tmp[:m])
+                    resr[lo_:lo_ + m].copy_(tmp[:m])
         if not async_op:
             finish()
             return res
         return res, _TorchWork(work, finish)
     work = dist.gather(send, None, dst=dst, group=group, async_op=async_op)
     return (None, work) if async_op else None
+
+
+def part_bounds(m, nparts):
+    """frame offsets of ``nparts`` near-equal consecutive parts of a block of m frames (the same rule on every rank)"""
+    return [(m * p) // nparts for p in range(nparts + 1)]
+
+
+class PartGather:
+    """A frame-sharded array gathered to the root in ``nparts`` rounds, so that the transfer of the frames that are
+    finished rides under the compute of the ones that are not (a 600 s stream at 8 ranks: one gather of 158 MB per rank
+    after the compute is a quarter of the step; four gathers hide three of them).
+
+    Round p moves frames [b_p, b_{p+1}) of EVERY rank's block (b = part_bounds of that rank's block) with one
+    gather_frames call -- rank blocks concatenated in a staging buffer on the root -- and the root copies each block to
+    its place in the frame-ordered result (device copies on the gather's stream / after its work handle)."""
+
+    def __init__(self, shard, nparts, group=None, dst=0, comm=None, stream=None):
+        self.shard, self.nparts, self.group, self.dst, self.comm, self.stream = shard, int(nparts), group, dst, comm, stream
+        self.sizes = shard_sizes(shard)
+        self.bounds = [part_bounds(m, self.nparts) for m in self.sizes]
+        self.first = [sum(self.sizes[:r]) for r in range(shard.world)]
+        self._stage = {}
+
+    def part_range(self, p, rank=None):
+        """(lo, hi) inside the block of ``rank`` (default: this shard's rank) that round p moves"""
+        b = self.bounds[self.shard.rank if rank is None else rank]
+        return b[p], b[p + 1]
+
+    def gather_part(self, p, local_part, result=None, async_op=False):
+        """local_part: this rank's frames part_range(p) ([m][F][R+1]); result: the root's [nchunks][F][R+1] array the
+        parts are assembled into (None elsewhere).  Returns a work handle (async_op) or None."""
+        import torch
+        counts = [self.bounds[r][p + 1] - self.bounds[r][p] for r in range(self.shard.world)]
+        F, cols = local_part.shape[1], local_part.shape[2]
+        stage = None
+        if result is not None:
+            # one staging block per round (rounds of one pass may be in flight together; the same round of the next
+            # pass reuses its block: the caller waits for a round's previous work before issuing it again)
+            shape = (sum(counts), F, cols)
+            stage = self._stage.get(p)
+            if stage is None or tuple(stage.shape) != shape or stage.device != result.device:
+                stage = self._stage[p] = torch.empty(shape, dtype=torch.complex64, device=result.device)
+        got = gather_frames(local_part, self.shard, self.group, self.dst, async_op, stage, self.comm, self.stream, counts)
+        res, work = got if async_op else (got, None)
+
+        def place():
+            if res is None:
+                return
+            off = 0
+            for r in range(self.shard.world):
+                if counts[r]:
+                    lo = self.first[r] + self.bounds[r][p]
+                    result[lo:lo + counts[r]].copy_(res[off:off + counts[r]], non_blocking=True)
+                off += counts[r]
+        if not async_op:
+            place()
+            return None
+        return _PlacedWork(work, place, self.comm, self.stream, result)
+
+
+class _PlacedWork:
+    """work handle of one PartGather round: the root's placement copies follow the gather (on its stream for the C-ABI
+    path, after the handle for torch's)"""
+
+    def __init__(self, work, place, comm, stream, result):
+        self.work, self.place, self.done = work, place, False
+        if comm is not None and result is not None:
+            import torch
+            st = torch.cuda.current_stream(result.device) if stream is None else stream
+            with torch.cuda.stream(st):                 # ordered after prc_gather_frames on the same stream
+                place()
+            self.done = True
+            self.ev = torch.cuda.Event()
+            self.ev.record(st)
+
+    def wait(self):
+        self.work.wait()
+        if not self.done:
+            self.place()
+            self.done = True
+        elif hasattr(self, "ev"):
+            self.ev.synchronize()
 
 
 class _TorchWork:
@@ -352,32 +445,47 @@ class HipBackend:
                 self._clean_range(ref_pad, srv_pad, out, c0, c1 - c0, self._stream())
         return out
 
-    def _ls_ranges(self, nlocal):
+    def _ls_ranges(self, nlocal, sub=None):
         """[c0, c1) chunk ranges of the clutter launches: sub-batches of ``sub`` chunks, a remainder of at most
         LS_HALO chunks folded into the launch before it; NLMS takes every chunk in one launch"""
         if self.clutter != "ls":
             return [(0, nlocal)] if nlocal > 0 else []
+        sub = self.sub if sub is None else sub
         out, c0 = [], 0
         while c0 < nlocal:
-            c1 = min(c0 + self.sub, nlocal)
+            c1 = min(c0 + sub, nlocal)
             if nlocal - c1 <= self.LS_HALO:
                 c1 = nlocal
             out.append((c0, c1))
             c0 = c1
         return out
 
-    def frames(self, ref_pad, clean_pad, offsets_first, nframes, out=None, f_lo=0, f_hi=None, stream=None):
-        """fast_xambg on overlapped frames [f_lo, f_hi) (stride C; frame 0 at element offsets_first)."""
+    def frames(self, ref_pad, clean_pad, offsets_first, nframes, out=None, f_lo=0, f_hi=None, stream=None,
+               cuts=None, on_frames=None, tstream=None):
+        """fast_xambg on overlapped frames [f_lo, f_hi) (stride C; frame 0 at element offsets_first).
+        cuts: frame indices at which a CAF launch must end (besides every ``batch`` frames); on_frames(lo, hi, event)
+        is called after the launch that completes frames [lo, hi) has been enqueued, with an event recorded behind it
+        on the launch stream (``tstream``: the torch stream object when ``stream`` is given as a raw pointer) -- together
+        they let a caller start moving finished frames (PartGather) while the rest is still being computed."""
         torch = self.torch
         if out is None:
             out = torch.empty((nframes, self.F, self.R + 1), dtype=torch.complex64, device=self.device)
         f_hi = nframes if f_hi is None else f_hi
+        stops = sorted({c for c in (cuts or ()) if f_lo < c < f_hi} | {f_hi})
         with torch.cuda.device(self.device):
-            for f0 in range(f_lo, f_hi, self.batch):
-                nb = min(self.batch, f_hi - f0)
-                off = offsets_first + f0 * self.C
-                self.caf.execute(ref_pad[off:], clean_pad[off:], out[f0:], nb, self.C, self.cpi,
-                                 self.window, self._stream() if stream is None else stream)
+            f0 = f_lo
+            for stop in stops:
+                while f0 < stop:
+                    nb = min(self.batch, stop - f0)
+                    off = offsets_first + f0 * self.C
+                    self.caf.execute(ref_pad[off:], clean_pad[off:], out[f0:], nb, self.C, self.cpi,
+                                     self.window, self._stream() if stream is None else stream)
+                    f0 += nb
+                if on_frames is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(tstream if tstream is not None else torch.cuda.current_stream(self.device))
+                    on_frames(f_lo, stop, ev)
+                    f_lo = stop
         return out
 
     def frames_multi(self, ref_pads, clean_pad, offsets_first, nframes, outs=None, stream=None):
@@ -405,14 +513,20 @@ class HipBackend:
         clean = self.clean(ref_pads[clutter_ref], srv_pad, nlocal)
         return self.frames_multi(ref_pads, clean, offsets_first, nframes, outs)
 
-    def run(self, ref_pad, srv_pad, nlocal, offsets_first, nframes, out=None):
+    def run(self, ref_pad, srv_pad, nlocal, offsets_first, nframes, out=None, cuts=None, on_frames=None):
         """clean + frames for one resident shard.  With ``overlap`` the LS chain runs sub-batch by
         sub-batch on one stream and the CAF of every frame whose three chunks are already clean
         follows on a second stream (frame j needs local chunk j + offsets_first/C + 1).
         out: optional preallocated [>= nframes][F][R+1] complex64 tensor for the maps."""
-        if not self.overlap or nlocal <= self.sub + self.LS_HALO:
+        # a shard that fits ONE LS launch (config 4 at 8 ranks: 152 chunks) is still cut in two, so that one half's
+        # latency-bound solves and the first frames' CAF run under the other half's HBM-bound passes (measured on one
+        # GPU, `bench.py --workload cfg4 --shard-of 3/8`: 8.0 -> 7.7 ms per 150-frame shard)
+        sub = self.sub
+        if self.overlap and self.nls >= 2 and 128 <= nlocal <= self.sub + self.LS_HALO:
+            sub = -(-nlocal // 2)
+        if not self.overlap or nlocal <= sub + self.LS_HALO:
             clean = self.clean(ref_pad, srv_pad, nlocal)
-            return self.frames(ref_pad, clean, offsets_first, nframes, out)
+            return self.frames(ref_pad, clean, offsets_first, nframes, out, cuts=cuts, on_frames=on_frames)
         import ctypes
         torch = self.torch
         clean = self._clean_target(srv_pad)
@@ -425,7 +539,7 @@ class HipBackend:
         first_chunk = offsets_first // self.C
         done = 0
         with torch.cuda.device(self.device):
-            for idx, (c0, c1) in enumerate(self._ls_ranges(nlocal)):
+            for idx, (c0, c1) in enumerate(self._ls_ranges(nlocal, sub)):
                 k = idx % self.nls
                 st = self.s_ls_all[k]
                 self._clean_range(ref_pad, srv_pad, clean, c0, c1 - c0, ctypes.c_void_p(st.cuda_stream),
@@ -437,7 +551,8 @@ class HipBackend:
                 ready = nframes if c1 == nlocal else max(min(nframes, c1 - 1 - first_chunk), 0)
                 if ready > done:
                     self.frames(ref_pad, clean, offsets_first, nframes, out, done, ready,
-                                ctypes.c_void_p(self.s_caf.cuda_stream))
+                                ctypes.c_void_p(self.s_caf.cuda_stream), cuts=cuts, on_frames=on_frames,
+                                tstream=self.s_caf)
                     done = ready
         for st in self.s_ls_all:
             main.wait_stream(st)

@@ -150,3 +150,51 @@ def test_cfg4_stream_of_1199_frames_sharded_over_8_ranks():
     ref, srv = _stream_1199()
     single = StreamProcessor(_CheapBackend(8, 4, 3)).process(ref, srv).numpy()
     assert full.shape == (1199, 4, 3) and np.array_equal(full, single)
+
+
+def _part_worker(rank, world, port, q):
+    from passiveradar_amd.stream import PartGather, plan_shard, shard_sizes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total, F, cols, nparts = 1199 if world == 8 else 11, 3, 2, 4
+    sh = plan_shard(total, rank, world)
+    mine = torch.arange(sh.frame_lo, sh.frame_hi, dtype=torch.float32).reshape(-1, 1, 1).repeat(1, F, cols).to(torch.complex64)
+    mine = mine + 1j * float(rank)
+    pg = PartGather(sh, nparts)
+    result = torch.zeros((total, F, cols), dtype=torch.complex64) if rank == 0 else None
+    works = []
+    for p in range(nparts):
+        a, b = pg.part_range(p)
+        if p % 2:                                   # both forms of the call
+            pg.gather_part(p, mine[a:b], result)
+        else:
+            works.append(pg.gather_part(p, mine[a:b], result, async_op=True))
+    for w in works:
+        w.wait()
+    if rank == 0:
+        sizes = shard_sizes(sh)
+        owner = torch.cat([torch.full((m,), float(r)) for r, m in enumerate(sizes)])
+        exp = torch.arange(total, dtype=torch.float32).reshape(-1, 1, 1).repeat(1, F, cols).to(torch.complex64)
+        exp = exp + 1j * owner.reshape(-1, 1, 1)
+        q.put(bool(torch.equal(result, exp)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_part_gather_assembles_the_frame_ordered_array(world):
+    """PartGather: a frame-sharded array moved to the root in four rounds (what bench.py --workload cfg4 does so that
+    finished frames travel under the compute of the rest): ragged shards (1199 frames over 8 ranks; 11 over 3, where
+    parts are empty), sync and async rounds, every frame at its place with its owner's mark"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_part_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    assert ok

@@ -49,6 +49,18 @@ def _worker(rank, world, port, q):
                 assert torch.equal(res.cpu(), exp), f"root {root}"
             else:
                 assert res is None
+        # the same array in three rounds (PartGather: finished frames travel while the rest is computed)
+        from passiveradar_amd.stream import PartGather
+        pg = PartGather(sh, 3, comm=comm)
+        result = torch.zeros((total, F, cols), dtype=torch.complex64, device=dev) if rank == 0 else None
+        works = [pg.gather_part(p_, mine[slice(*pg.part_range(p_))], result, async_op=True) for p_ in range(3)]
+        for w_ in works:
+            w_.wait()
+        if rank == 0:
+            sizes = shard_sizes(sh)
+            exp = torch.cat([torch.full((m, F, cols), float(r + 1), dtype=torch.complex64) for r, m in enumerate(sizes)])
+            exp += torch.arange(total, dtype=torch.float32).reshape(-1, 1, 1) * 1j
+            assert torch.equal(result.cpu(), exp), "PartGather"
         # the sharded stream driver against the unsharded pass on rank 0
         C, R, Fd, fs = 16384, 24, 64, 1.0e5
         ref, srv = scene.make_stream(3 * world + 1, C, fs, R, 2026)
