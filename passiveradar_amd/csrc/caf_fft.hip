@@ -117,17 +117,24 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
         //   [u(i) resident] issue v0(i) | FFT u(i) | issue v1(i) / u(i+1) | FFT v0 | ... | acc
         float2 un[16];
         float wn[16];
-        auto issue_u = [&](int n0) {
+        // nz: registers r >= nz lie beyond the piece for every lane (64 r >= cnt): not loaded, zero
+        auto issue_u = [&](int n0, int nz = 16) {
             const int rem = hi - n0 + 1;
             int cnt = rem < B ? rem : B;
             if (NV - n0 < cnt) cnt = NV - n0;
             const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + n0, clampu(cnt) * 8u);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) un[r] = prc_buf_load_c64(ru, vo8, 512u * r);
+            for (int r = 0; r < 16; ++r) {
+                if (r < 8 || (r < 12 && nz > 8) || nz > 12) un[r] = prc_buf_load_c64(ru, vo8, 512u * r);
+                else un[r] = make_float2(0.f, 0.f);
+            }
             if (HAS_WIN) {
                 const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + n0, clampu(cnt) * 4u);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) wn[r] = prc_buf_load_f32(rw, vo4, 256u * r);
+                for (int r = 0; r < 16; ++r) {
+                    if (r < 8 || (r < 12 && nz > 8) || nz > 12) wn[r] = prc_buf_load_f32(rw, vo4, 256u * r);
+                    else wn[r] = 0.f;
+                }
             }
         };
         // srv slots [0, cnt+LB-1) of lag block lb: frame offsets start .. with circular wrap (:82)
@@ -158,13 +165,33 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
             const int rem = hi - n0 + 1;
             const int cnt = rem < B ? rem : B;
             float2 u[16], v[NLB][16];
-            if (!PREFETCH) issue_u(n0);
+            // zero-padded reference piece (every span above 256 lags makes it at most 768 samples): registers 12..15
+            // (8..15 for a piece of at most 512) are zero in every lane -- loads, window products and the first-pass
+            // additions of the transform are skipped (wave-uniform branch; the prefetching two-lag-block form loads whole)
+            const int nz = PREFETCH ? 16 : (cnt <= 512 ? 8 : (cnt <= 768 ? 12 : 16));
+            if (nz == 8) {
+                issue_u(n0, 8);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
-            if (PREFETCH) issue_v(v[0], n0, cnt, lb0);
-            __builtin_amdgcn_sched_barrier(0);
-            fft1024_fwd(u, tile, tab, f);
+                for (int r = 0; r < 16; ++r)
+                    u[r] = r < 8 ? (HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r]) : make_float2(0.f, 0.f);
+                __builtin_amdgcn_sched_barrier(0);
+                fft1024_fwd<8>(u, tile, tab, f);
+            } else if (nz == 12) {
+                issue_u(n0, 12);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    u[r] = r < 12 ? (HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r]) : make_float2(0.f, 0.f);
+                __builtin_amdgcn_sched_barrier(0);
+                fft1024_fwd<12>(u, tile, tab, f);
+            } else {
+                if (!PREFETCH) issue_u(n0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
+                if (PREFETCH) issue_v(v[0], n0, cnt, lb0);
+                __builtin_amdgcn_sched_barrier(0);
+                fft1024_fwd(u, tile, tab, f);
+            }
 #pragma unroll
             for (int l = 0; l < NLB; ++l) {
                 __builtin_amdgcn_sched_barrier(0);

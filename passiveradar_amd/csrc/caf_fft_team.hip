@@ -118,7 +118,7 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
             // last piece, n_valid < n, the prefetch past the last piece).
             float2 un[16];
             float wn[16];
-            auto issue_u = [&](int n0) {
+            auto issue_u = [&](int n0, int nz = 16) {
 #ifdef CAFT_EXP_NOLOAD
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { un[r] = make_float2((float)(t + n0), (float)r); wn[r] = 0.5f; }
@@ -128,12 +128,19 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
                 int cnt = rem < B ? rem : B;
                 if (NV - n0 < cnt) cnt = NV - n0;
                 const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + n0, clampu(cnt) * 8u);
+                // registers beyond the piece (r >= nz: 256 r >= cnt) are zero for every thread: not even loaded
 #pragma unroll
-                for (int r = 0; r < 16; ++r) un[r] = prc_buf_load_c64(ru, vo8, 2048u * r);
+                for (int r = 0; r < 16; ++r) {
+                    if (r < 8 || (r < 12 && nz > 8) || nz > 12) un[r] = prc_buf_load_c64(ru, vo8, 2048u * r);
+                    else un[r] = make_float2(0.f, 0.f);
+                }
                 if (HAS_WIN) {
                     const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + n0, clampu(cnt) * 4u);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) wn[r] = prc_buf_load_f32(rw, vo4, 1024u * r);
+                    for (int r = 0; r < 16; ++r) {
+                        if (r < 8 || (r < 12 && nz > 8) || nz > 12) wn[r] = prc_buf_load_f32(rw, vo4, 1024u * r);
+                        else wn[r] = 0.f;
+                    }
                 }
             };
             // srv slots [0, cnt+LB-1) of this lag block: frame offsets start .. with circular wrap (:82)
@@ -181,27 +188,42 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
                 __builtin_amdgcn_sched_barrier(0);
                 ft4096_fwd<1>(v, f);
 #else
-            // high-occupancy form: nothing is loaded ahead (the other wavefronts of the SIMD cover the latency)
-            // and only u, v and the accumulator are ever live together
+            // high-occupancy form: nothing is loaded a piece ahead (the other wavefronts of the SIMD cover the latency);
+            // only u, v and the accumulator are ever live together, and the surveillance loads of a piece are issued
+            // before the reference transform so that they fly under it (round 3, -2 %)
             for (int n0 = lo; n0 <= hi_f; n0 += B) {
                 const int rem = hi_f - n0 + 1;
                 const int cnt = rem < B ? rem : B;
                 float2 u[16], v[16];
-                issue_u(n0);
+                // zero-padded reference piece: a piece of at most 2048 (3072) samples leaves registers 8..15 (12..15) of
+                // every thread zero -- their loads, window products and first-pass additions are skipped (uniform branch)
+                const int nz = cnt <= 2048 ? 8 : (cnt <= 3072 ? 12 : 16);
+                if (nz == 8) {
+                    issue_u(n0, 8);
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
-#ifdef CAFT_V_EARLY
-                issue_v(v, n0, cnt);                            // in flight under the transform of u
+                    for (int r = 0; r < 16; ++r)
+                        u[r] = r < 8 ? (HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r]) : make_float2(0.f, 0.f);
+                    issue_v(v, n0, cnt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ft4096_fwd<0, 8>(u, f);
+                } else if (nz == 12) {
+                    issue_u(n0, 12);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        u[r] = r < 12 ? (HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r]) : make_float2(0.f, 0.f);
+                    issue_v(v, n0, cnt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ft4096_fwd<0, 12>(u, f);
+                } else {
+                    issue_u(n0, 16);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
+                    issue_v(v, n0, cnt);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ft4096_fwd<0, 16>(u, f);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                ft4096_fwd<0>(u, f);
-                __builtin_amdgcn_sched_barrier(0);
-#else
-                __builtin_amdgcn_sched_barrier(0);
-                ft4096_fwd<0>(u, f);
-                __builtin_amdgcn_sched_barrier(0);
-                issue_v(v, n0, cnt);
-#endif
                 ft4096_fwd<1>(v, f);
 #endif
 #pragma unroll

@@ -111,10 +111,11 @@ __device__ __forceinline__ FtLane ft_setup(float2* lds, const float2* __restrict
 __device__ __forceinline__ void ft_team_sync() { FT_BARRIER(); }
 
 // Forward FFT: time layout -> frequency layout.  CUR: buffer of the cross-wave exchange (alternate 0, 1, 0, ...).
-template <int CUR>
+// NZ: registers x[NZ..15] are zero in every thread (a zero-padded piece of at most 256 NZ samples)
+template <int CUR, int NZ = 16>
 __device__ __forceinline__ void ft4096_fwd(float2 (&x)[16], const FtLane& f) {
     constexpr int T = (FT_NBUF == 2 ? CUR : 0) * FT_BUF, O = (FT_NBUF == 2 ? (CUR ^ 1) : 0) * FT_BUF;
-    dft16<1>(x);
+    dft16<1, NZ>(x);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) x[k1] = mul_tw<1>(x[k1], f.tw1[16 * k1]);
 #ifndef FT_EXP_NOX1

@@ -62,15 +62,41 @@ PRC_HD void bfly4(float2& x0, float2& x1, float2& x2, float2& x3) {
     x3 = f2sub(d02, t);
 }
 
-// In-register 16-point DFT, natural order in and out: v[k] = sum_n v[n] W_16^(DIR*n*k)
+// radix-4 butterfly whose third / third and fourth inputs are known to be zero (zero-padded transforms)
 template <int DIR>
+PRC_HD void bfly4_z3(float2& x0, float2& x1, float2& x2, float2& x3) {     // x3 == 0
+    const float2 s02 = f2add(x0, x2), d02 = f2sub(x0, x2);
+    const float2 t = mul_mi<DIR>(x1);
+    x0 = f2add(s02, x1);
+    x2 = f2sub(s02, x1);
+    x1 = f2add(d02, t);
+    x3 = f2sub(d02, t);
+}
+template <int DIR>
+PRC_HD void bfly4_z23(float2& x0, float2& x1, float2& x2, float2& x3) {    // x2 == x3 == 0
+    const float2 a = x0, b = x1;
+    const float2 t = mul_mi<DIR>(b);
+    x0 = f2add(a, b);
+    x2 = f2sub(a, b);
+    x1 = f2add(a, t);
+    x3 = f2sub(a, t);
+}
+
+// In-register 16-point DFT, natural order in and out: v[k] = sum_n v[n] W_16^(DIR*n*k).
+// NZ: inputs v[NZ..15] are known to be zero (16, 12 or 8): the first radix-4 pass then skips their additions.
+template <int DIR, int NZ = 16>
 PRC_HD void dft16(float2 (&v)[16]) {
     constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
     constexpr float S1 = 0.38268343236508977f;   // sin(pi/8)
     constexpr float RH = 0.70710678118654752f;   // sqrt(1/2)
+    static_assert(NZ == 16 || NZ == 12 || NZ == 8, "dft16: zero tail of 0, 4 or 8 inputs");
     // step 1: radix-4 over a (n = 4a + b): v[4c + b] = t_b[c]
 #pragma unroll
-    for (int b = 0; b < 4; ++b) bfly4<DIR>(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    for (int b = 0; b < 4; ++b) {
+        if (NZ == 16) bfly4<DIR>(v[b], v[4 + b], v[8 + b], v[12 + b]);
+        else if (NZ == 12) bfly4_z3<DIR>(v[b], v[4 + b], v[8 + b], v[12 + b]);
+        else bfly4_z23<DIR>(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    }
     // step 2: t_b[c] *= W_16^(b*c)
     v[5] = mul_cs<DIR>(v[5], C1, S1);      // b=1,c=1: e=1
     v[9] = mul_cs<DIR>(v[9], RH, RH);      // b=1,c=2: e=2
@@ -178,9 +204,11 @@ __device__ __forceinline__ void quad_dft4_bwd(float2 (&p)[16], const FftLane& f)
 }
 
 // Forward FFT: natural (lane n2, reg n1) -> permuted frequency layout.
+// NZ: registers x[NZ..15] are zero in every lane (a zero-padded piece of at most 64 NZ samples)
+template <int NZ = 16>
 __device__ __forceinline__ void fft1024_fwd(float2 (&x)[16], float2* tile, const float2* tab,
                                             const FftLane& f) {
-    dft16<1>(x);
+    dft16<1, NZ>(x);
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) x[k1] = mul_tw<1>(x[k1], tab[k1 * 64 + f.lane]);
 #pragma unroll
