@@ -59,6 +59,14 @@ __device__ __forceinline__ void pk_cmac_conj(v2f& acc, v2f w, v2f u) {
                  "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
                  : "+v"(acc) : "v"(w), "v"(u));
 }
+// acc = conj(w) * u (first product of a chain: no zero-initialised accumulator)
+__device__ __forceinline__ v2f pk_cmul_conj(v2f w, v2f u) {
+    v2f acc;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
+        : "=&v"(acc) : "v"(w), "v"(u));
+    return acc;
+}
 // w += u * conj(c) :  (w.x, w.y) += c.x (u.x, u.y);  (w.x, w.y) += c.y (u.y, -u.x)
 __device__ __forceinline__ void pk_cmac_bconj(v2f& w, v2f u, v2f c) {
     asm("v_pk_fma_f32 %0, %2, %1, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n"
@@ -72,6 +80,35 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Both sums of a step (re, im of conj(w).u) in ONE reduction: v_permlane32_swap puts the real partials of the upper half
+// next to the imaginary partials of the lower half, one add folds the halves, four DPP adds reduce the 16-lane rows, and
+// the four row sums are read back -- 12 instructions where two separate all-lane sums took 22.
+__device__ __forceinline__ void wave_allsum2(float& yr, float& yi) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(yr), __float_as_int(yi), false, false);
+    float v = __int_as_float(sw[0]) + __int_as_float(sw[1]);     // lanes 0-31: re(l) + re(l+32); lanes 32-63: im
+    v += dpp_f(v, 0);
+    v += dpp_f(v, 1);
+    v += dpp_f(v, 2);
+    v += dpp_f(v, 3);
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    yr = a + b;
+    yi = c + d;
+}
+// lane l <- lane l-1 across the whole wavefront; lane 0 keeps `lane0`
+__device__ __forceinline__ float wave_shr1(float lane0, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0), __float_as_int(src), 0x138, 0xF, 0xF, false));
+}
+
+// Tap layout (round 3): consecutive taps per lane.  The first A = T - 64 (TPL - 1) lanes hold TPL taps, the others TPL - 1
+// (A TPL + (64 - A)(TPL - 1) = T exactly: no ragged end anywhere), lane l's first tap being i0(l).  From one step to the next
+// every tap's input sample moves to the next tap: inside a lane that is a register RENAME (the step loop is unrolled TPL-fold
+// over a rotating register index, so nothing moves), across lanes it is one wave_shr DPP move of the lane's last valid
+// sample, and the new sample enters lane 0 from a broadcast LDS read.  A short lane's spare register is re-zeroed every step
+// (its index is a compile-time constant).  Round 2 spread taps lane-minor (tap = lane + 64 t) and re-read the whole window
+// from LDS every step: 17 ds_read_b64 per step at T = 1034 against 1 now, and its two all-lane sums are one (wave_allsum2).
 template <int TPL, int MAXW>
 __global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -87,19 +124,22 @@ __global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
     float2* __restrict__ out = a.out + (int64_t)b * a.out_stride;
     const int T = a.T;
     const int64_t nsteps = a.n - T;   // k = 0..nsteps-1 (may be <= 0)
+    const int A = T - 64 * (TPL - 1);                   // 1 <= A <= 64 lanes with TPL taps
+    const bool full = lane < A;
+    const int i0 = full ? lane * TPL : A * TPL + (lane - A) * (TPL - 1);
+    const int ntap = full ? TPL : TPL - 1;
 
     v2f w[TPL];
 #pragma unroll
     for (int t = 0; t < TPL; ++t) {
-        const int i = lane + 64 * t;
-        const float2 w0 = (a.taps_in && i < T) ? a.taps_in[(int64_t)b * T + i] : make_float2(0.f, 0.f);
+        const float2 w0 = (a.taps_in && t < ntap) ? a.taps_in[(int64_t)b * T + i0 + t] : make_float2(0.f, 0.f);
         w[t] = v2f{w0.x, w0.y};
     }
     // out[0:L] = 0 and out[n-peek:] = 0 (:231)
     for (int64_t i = lane; i < a.n; i += 64)
         if (i < a.L || i >= a.L + (nsteps > 0 ? nsteps : 0)) out[i] = make_float2(0.f, 0.f);
 
-    const int WIN = 64 * TPL;   // >= T; taps i >= T are held at zero through zero u
+    const int WIN = 64 * TPL;   // >= T
     for (int64_t k0 = 0; k0 < nsteps; k0 += KT) {
         const int64_t rem = nsteps - k0;
         const int cnt = rem < KT ? (int)rem : KT;
@@ -120,75 +160,76 @@ __global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
         // double and the running sum is good to 1e-16 of the largest energy seen, so the slid value equals the
         // reference's per-step sum to float32 accuracy whatever the input does (four f64 FMAs per step).
         double energy;
-        {   // the window's first sum in double as well (a float32 sum would leave a 1e-7 E bias for the whole window)
+        v2f P[TPL];                                    // the lane's samples, rotating: tap t of step j is P[(t - j) mod TPL]
+        {
             double e0 = 0.0;
 #pragma unroll
             for (int t = 0; t < TPL; ++t) {
-                const int i = lane + 64 * t;
-                const float2 v = Rw[WIN - 1 - i];
-                if (i < T) e0 = fma((double)v.x, (double)v.x, fma((double)v.y, (double)v.y, e0));
+                float2 v = Rw[WIN - 1 - (i0 + t)];
+                if (t >= ntap) v = make_float2(0.f, 0.f);
+                e0 = fma((double)v.x, (double)v.x, fma((double)v.y, (double)v.y, e0));
+                P[t] = v2f{v.x, v.y};
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) e0 += __shfl_xor(e0, m, 64);
             energy = e0;
         }
-        // One step: dot (registers), two DPP reductions, AXPY.  The sliding window of the NEXT step
-        // is fetched from LDS while this step reduces (ua/ub swap roles, loop unrolled by two), so
-        // the only latency left on the critical path is the reduction itself.
-        auto fetch = [&](v2f (&u)[TPL], int kk) {
+        for (int kk0 = 0; kk0 < cnt; kk0 += TPL) {
 #pragma unroll
-            for (int t = 0; t < TPL; ++t) {
-                const int i = lane + 64 * t;
-                float2 v = Rw[kk + WIN - 1 - i];
-                if (t == TPL - 1 && i >= T) v = make_float2(0.f, 0.f);   // only the last group can overhang T
-                u[t] = v2f{v.x, v.y};
+            for (int j = 0; j < TPL; ++j) {
+                const int kk = kk0 + j;
+                if (kk < cnt) {                        // uniform (no break: the unrolled body keeps its constant register indices)
+                    // the sample that enters tap 0 at the next step (also the one entering the energy window), the one leaving it
+                    const float2 vin = Rw[kk + WIN], vout = Rw[kk + WIN - T];
+                    const float2 d = D[kk];
+                    // conj(w) . u on packed FMAs, two chains opened by a product (no zeroed accumulators to set up)
+                    v2f acc0 = pk_cmul_conj(w[0], P[(0 - j + TPL) % TPL]);
+                    v2f acc1 = TPL > 1 ? pk_cmul_conj(w[1 % TPL], P[(1 - j + TPL) % TPL]) : v2f{0.f, 0.f};
+#pragma unroll
+                    for (int t = 2; t < TPL; ++t) pk_cmac_conj((t & 1) ? acc1 : acc0, w[t], P[(t - j + TPL) % TPL]);
+                    const v2f ysum = acc0 + acc1;
+                    float yr = ysum.x, yi = ysum.y;
+                    wave_allsum2(yr, yi);
+                    const float en = (float)energy;
+                    {
+                        const double ix = (double)vin.x, iy = (double)vin.y, ox = (double)vout.x, oy = (double)vout.y;
+                        energy = fma(ix, ix, energy);
+                        energy = fma(iy, iy, energy);
+                        energy = fma(-ox, ox, energy);
+                        energy = fma(-oy, oy, energy);
+                    }
+                    const float er = d.x - yr, ei = d.y - yi;
+                    // coefficient mu conj(e) / (u^H u): hardware reciprocal (1 ulp) instead of the twelve-instruction IEEE
+                    // division -- the step size is a tuning constant, its last bit is not the reference's either
+                    const float s = a.mu * __builtin_amdgcn_rcpf(en);
+                    const v2f c = {er * s, ei * s};
+#pragma unroll
+                    for (int t = 0; t < TPL; ++t) pk_cmac_bconj(w[t], P[(t - j + TPL) % TPL], c);
+                    if (lane == 0) D[kk] = make_float2(er, ei);
+                    // shift: a lane's last VALID sample (tap TPL-1, or TPL-2 in a short lane) goes to the next lane's
+                    // tap 0, the new sample to lane 0's; the slot of the old last tap, P[TPL-1-j], is tap 0 of step j+1
+                    v2f carry = P[TPL - 1 - j];
+                    if (TPL > 1) {
+                        const v2f prev = P[(2 * TPL - 2 - j) % TPL];      // tap TPL-2 of this step
+                        carry = full ? carry : prev;
+                    }
+                    P[TPL - 1 - j] = v2f{wave_shr1(vin.x, carry.x), wave_shr1(vin.y, carry.y)};
+                    if (TPL > 1) {
+                        // a short lane's spare register: tap TPL-1 of step j+1 (what was tap TPL-2) stays zero
+                        if (!full) P[(2 * TPL - 2 - j) % TPL] = v2f{0.f, 0.f};
+                    } else if (!full) {
+                        P[0] = v2f{0.f, 0.f};                               // one tap per lane: lanes beyond T hold nothing
+                    }
+                }
             }
-        };
-        auto step = [&](const v2f (&u)[TPL], v2f (&unext)[TPL], int kk) {
-            // conj(w) * u on packed FMAs (one wavefront per SIMD only reaches half the scalar-FMA issue rate; the
-            // packed form runs at full rate), four independent accumulators to keep the chains short
-            v2f acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-            for (int t = 0; t < TPL; ++t) pk_cmac_conj(acc[t & 3], w[t], u[t]);
-            const v2f ysum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            float yr = ysum.x, yi = ysum.y;
-            fetch(unext, kk + 1);                    // independent of this step's result
-            yr = wave_allsum(yr);
-            yi = wave_allsum(yi);
-            const float en = (float)energy;
-            {   // slide the energy to the next step (wave-uniform LDS reads, broadcast)
-                const float2 vin = Rw[kk + WIN], vout = Rw[kk + WIN - T];
-                const double ix = (double)vin.x, iy = (double)vin.y, ox = (double)vout.x, oy = (double)vout.y;
-                energy = fma(ix, ix, energy);
-                energy = fma(iy, iy, energy);
-                energy = fma(-ox, ox, energy);
-                energy = fma(-oy, oy, energy);
-            }
-            const float2 d = D[kk];
-            const float er = d.x - yr, ei = d.y - yi;
-            const float s = a.mu / en;               // coefficient mu * conj(e) / (u^H u)
-            const v2f c = {er * s, ei * s};         // w += u * conj(c')  with c' = (er, ei) s  (mu conj(e) / (u^H u))
-#pragma unroll
-            for (int t = 0; t < TPL; ++t) pk_cmac_bconj(w[t], u[t], c);
-            if (lane == 0) D[kk] = make_float2(er, ei);
-        };
-        v2f ua[TPL], ub[TPL];
-        fetch(ua, 0);
-        int kk = 0;
-        for (; kk + 2 <= cnt; kk += 2) {
-            step(ua, ub, kk);
-            step(ub, ua, kk + 1);
         }
-        if (kk < cnt) step(ua, ub, kk);
         wave_lds_fence();
         for (int x = lane; x < cnt; x += 64) out[a.L + k0 + x] = D[x];
     }
     if (a.taps_out) {
 #pragma unroll
-        for (int t = 0; t < TPL; ++t) {
-            const int i = lane + 64 * t;
-            if (i < T) a.taps_out[(int64_t)b * T + i] = make_float2(w[t].x, w[t].y);
-        }
+        for (int t = 0; t < TPL; ++t)
+            if (t < ntap) a.taps_out[(int64_t)b * T + i0 + t] = make_float2(w[t].x, w[t].y);
     }
 }
 
