@@ -5,7 +5,9 @@
 // The recursion is strictly sequential in k; the parallelism is the T taps (spread over the 64
 // lanes of ONE wavefront so that no workgroup barrier sits on the critical path) and the
 // independent streams (one wavefront each).  This is a VALU-issue-bound wavefront dot-product +
-// AXPY loop -- not HBM-bound (24 B/sample) and not MFMA-shaped.
+// AXPY loop -- not HBM-bound (24 B/sample) and not MFMA-shaped.  A step is 68 packed FMAs (the 2 x 17
+// complex MACs of T = 1034) + 41 other vector instructions: 274 ns alone on a SIMD, 223 ns per step with
+// three streams per SIMD (round 2: 128 instructions, 374 / 280 ns).
 //
 // Placement matters more than anything else here: a SIMD that gets two of these wavefronts while its
 // neighbour gets none runs 1.5x longer, and with one-wavefront workgroups the dispatcher does exactly that
@@ -40,18 +42,6 @@ __device__ __forceinline__ float dpp_f(float x, const int which) {
     }
     return __int_as_float(r);
 }
-__device__ __forceinline__ float wave_allsum(float v) {
-    v += dpp_f(v, 0);
-    v += dpp_f(v, 1);
-    v += dpp_f(v, 2);
-    v += dpp_f(v, 3);
-    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (a + b) + (c + d);
-}
-
 typedef float v2f __attribute__((ext_vector_type(2)));
 // acc += conj(w) * u :  (acc.x, acc.y) += w.x (u.x, u.y);  (acc.x, acc.y) += w.y (u.y, -u.x)
 __device__ __forceinline__ void pk_cmac_conj(v2f& acc, v2f w, v2f u) {
@@ -277,12 +267,18 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
     PRC_REQUIRE(lds <= lds_cu, PRC_EUNSUPPORTED, "prc_nlms_execute: %d taps do not fit the LDS window", T);
     if (lds < 84 * 1024) lds = 84 * 1024;              // more than half a CU's LDS: one workgroup per CU
     const int grid = (int)ceil_div64(nstreams, nw);
+    int dev = 0;
+    PRC_HIP(hipGetDevice(&dev));
     // one instantiation per taps-per-lane count: the kernel masks only the LAST 64-tap group against T, so the
     // group count must be exact (a coarser bucket list once left whole groups beyond T unmasked)
 #define PRC_NLMS_CASE(G, W)                                                                     \
     case G: {                                                                                   \
-        PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nlms_kernel<G, W>),          \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu));  \
+        static bool attr_done[16] = {false};      /* the LDS opt-in is per device and per instantiation, not per launch */ \
+        if (dev < 0 || dev >= 16 || !attr_done[dev]) {                                          \
+            PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&nlms_kernel<G, W>),      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cu)); \
+            if (dev >= 0 && dev < 16) attr_done[dev] = true;                                    \
+        }                                                                                       \
         hipLaunchKernelGGL((nlms_kernel<G, W>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, a); \
         PRC_LAUNCH_CHECK();                                                                     \
         return PRC_OK;                                                                          \
