@@ -251,12 +251,13 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
     a.nstreams = nstreams;
     // wavefronts per workgroup = per CU: one per SIMD up to 1024 streams, then two, then three (register file permitting)
     const int maxw = tpl <= 17 ? 12 : (tpl <= 24 ? 8 : 4);
-    // measured step time of a SIMD holding 1 / 2 / 3 of these wavefronts, relative: 1.0 / 1.55 / 2.2 (MI355X)
+    // measured step time of a SIMD holding 1 / 2 / 3 of these wavefronts, relative: 1.0 / 1.68 / 2.44 (MI355X, round 3:
+    // 274 / 459 / 669 ns per step at T = 1034)
     int nw = 4;
     double best = 1e30;
     for (int w = 4; w <= maxw; w += 4) {
         const double rounds = (double)ceil_div64(ceil_div64(nstreams, w), 256);
-        const double cost = rounds * (w == 4 ? 1.0 : (w == 8 ? 1.55 : 2.2));
+        const double cost = rounds * (w == 4 ? 1.0 : (w == 8 ? 1.68 : 2.44));
         if (cost < best) { best = cost; nw = w; }
     }
     const size_t lds_cu = 160 * 1024;
