@@ -327,7 +327,10 @@ class HipBackend:
     def __init__(self, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
                  doppler_bins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), clutter="ls",
                  batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, overlap=True,
-                 ls_method=0, nsub=1, ls_streams=3, nref=1):
+                 ls_method=0, nsub=1, ls_streams=3, nref=1, ls_reg=1.0):
+        """clutter: "ls" = LS_Filter_Multiple over ``doppler_bins`` (main.py:169-176, the reference's choice),
+        "ls_direct" = LS_Filter (clutter_removal.py:6-56: circular data matrix, ``ls_reg`` on the Gram diagonal, one
+        bin -- SURVEY 8's config-2 "LS_Filter variant"), "nlms" = NLMS_filter with step ``nlms_mu``, None = no canceller."""
         import torch
         from . import engine
         from .range_doppler_processing import _named_window
@@ -338,7 +341,11 @@ class HipBackend:
         self.R, self.F = int(num_range_cells), int(num_doppler_cells)
         self.fs = float(IF_sample_rate)
         self.bins = tuple(float(b) for b in doppler_bins)
+        if clutter not in ("ls", "ls_direct", "nlms", None):
+            raise ValueError(f"HipBackend: unknown clutter canceller {clutter!r}")
         self.clutter = clutter
+        self.ls_like = clutter in ("ls", "ls_direct")       # block least-squares cancellers: plans, sub-batches, chains
+        self.ls_reg = float(ls_reg)
         self.batch = int(batch)
         self.nref = max(1, int(nref))      # reference channels per surveillance channel (run_multi / frames_multi)
         self.nlms_mu = float(nlms_mu)
@@ -346,21 +353,21 @@ class HipBackend:
         # LS launches of batch/nsub chunks.  Measured on MI355X (config 2, two LS chains in flight): 256-chunk launches
         # (nsub = 1) 20.45 k frames/s, 128-chunk launches (nsub = 2) 19.56 k -- the latency-bound Durbin / solve kernels
         # are per launch, so fewer, fuller launches win now that the second chain provides the overlap
-        self.overlap = bool(overlap) and clutter == "ls" and self.batch >= 128
+        self.overlap = bool(overlap) and self.ls_like and self.batch >= 128
         # chunks per LS launch; NLMS is one wavefront per chunk, so splitting a batch would only idle SIMDs
-        self.sub = -(-self.batch // max(int(nsub), 1)) if (self.overlap and clutter == "ls") else self.batch
+        self.sub = -(-self.batch // max(int(nsub), 1)) if (self.overlap and self.ls_like) else self.batch
         with torch.cuda.device(self.device):
             self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch * self.nref, caf_method, doppler_method)
             # The LS chain of a sub-batch is a strictly sequential string of kernels, a third of them latency-bound
             # (one Levinson-Durbin per block, per-bin solves: a few wavefronts busy).  Several plans on as many streams
             # run alternate sub-batches concurrently, so one chain's solves sit under the others' HBM-bound passes
             # (measured at config 2: 1 chain 18.7 k frames/s, 2: 20.25 k, 3: 20.46 k, 4: 20.51 k).
-            self.nls = max(1, int(ls_streams)) if (self.overlap and clutter == "ls") else 1
+            self.nls = max(1, int(ls_streams)) if (self.overlap and self.ls_like) else 1
             # LS_HALO spare blocks per plan: a shard of m frames filters m + 2 chunks (one halo chunk each side,
             # plan_shard); when the last sub-batch would be no more than the halo it rides in the launch before it
             # instead of paying a latency-bound chain of its own (config 4 at 8 ranks: 150 frames, 152 chunks)
-            self.ls_plans = [engine.LsPlan(self.C, self.R, 10, False, self.sub + self.LS_HALO, ls_method)
-                             for _ in range(self.nls)] if clutter == "ls" else []
+            self.ls_plans = [engine.LsPlan(self.C, self.R, 10, clutter == "ls_direct", self.sub + self.LS_HALO, ls_method)
+                             for _ in range(self.nls)] if self.ls_like else []
             self.ls = self.ls_plans[0] if self.ls_plans else None
             if isinstance(window, (tuple, str)):
                 w = _named_window(window, self.cpi)
@@ -428,6 +435,9 @@ class HipBackend:
         if self.clutter == "ls":
             (plan or self.ls).execute(ref_pad[off:], srv_pad[off:], out[off:], nb, C, C, self.fs, self.bins, 0.0,
                                       None, stream)
+        elif self.clutter == "ls_direct":
+            (plan or self.ls).execute(ref_pad[off:], srv_pad[off:], out[off:], nb, C, C, self.fs, (0.0,), self.ls_reg,
+                                      None, stream)
         else:
             self.engine.nlms_execute(ref_pad[off:], srv_pad[off:], out[off:], C, self.R, self.nlms_mu, 10,
                                      None, None, nb, C, C, stream)
@@ -448,7 +458,7 @@ class HipBackend:
     def _ls_ranges(self, nlocal, sub=None):
         """[c0, c1) chunk ranges of the clutter launches: sub-batches of ``sub`` chunks, a remainder of at most
         LS_HALO chunks folded into the launch before it; NLMS takes every chunk in one launch"""
-        if self.clutter != "ls":
+        if not self.ls_like:
             return [(0, nlocal)] if nlocal > 0 else []
         sub = self.sub if sub is None else sub
         out, c0 = [], 0

@@ -343,3 +343,28 @@ def test_bench_cfg4_maps_against_an_independent_pass(tmp_path):
     rp, cp = np.concatenate((pad, rh, pad)), np.concatenate((pad, clean, pad))
     exp = O.fast_xambg(rp[fi * C:fi * C + n], cp[fi * C:fi * C + n], R, F, n, get_window(("kaiser", 5.0), n))[:, :, 0]
     assert rel_err(got[list(d["frame_index"]).index(fi)], exp) < 1e-4
+
+
+def test_stream_with_the_ls_filter_variant():
+    """SURVEY 8's config-2 "LS_Filter variant": the stream backend with clutter="ls_direct" runs LS_Filter
+    (clutter_removal.py:6-56: circular data matrix, reg = 1 on the Gram diagonal) per hop chunk, then the overlapped
+    CAF -- equal to the drop-in called chunk by chunk and to the oracle end to end"""
+    from oracle import np_oracle as O
+    from passiveradar_amd import scene
+    from passiveradar_amd.clutter_removal import LS_Filter
+    from passiveradar_amd.stream import HipBackend, StreamProcessor
+    C, R, F, fs, nch = 16384, 24, 64, 1.0e5, 5
+    ref, srv = scene.make_stream(nch, C, fs, R, 777)
+    be = HipBackend(2 * C, R, F, fs, clutter="ls_direct", batch=4)
+    got = StreamProcessor(be).process(ref, srv).cpu().numpy()
+    clean = np.concatenate([LS_Filter(ref[i * C:(i + 1) * C], srv[i * C:(i + 1) * C], R) for i in range(nch)])
+    exp_clean = np.concatenate([O.LS_Filter(ref[i * C:(i + 1) * C], srv[i * C:(i + 1) * C], R) for i in range(nch)])
+    assert rel_err(clean, exp_clean) < 1e-4
+    pad = np.zeros(C // 2, np.complex64)
+    rp, cp = np.concatenate((pad, ref, pad)), np.concatenate((pad, exp_clean.astype(np.complex64), pad))
+    w = np.kaiser(2 * C, 5.0)
+    for f in (0, 2, nch - 1):
+        exp = O.fast_xambg(rp[f * C:f * C + 2 * C], cp[f * C:f * C + 2 * C], R, F, 2 * C, w)[:, :, 0]
+        assert rel_err(got[f], exp) < 1e-4, f
+    with pytest.raises(ValueError):
+        HipBackend(2 * C, R, F, fs, clutter="svd")
