@@ -96,6 +96,13 @@ __device__ __forceinline__ float2 prc_buf_load_c64(__amdgpu_buffer_rsrc_t r, uns
     const prc_v2u x = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
     return make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
 }
+// two adjacent complex64 per lane in one 16-byte access (1 KB per wavefront instruction)
+typedef unsigned int prc_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void prc_buf_load_2c64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2& a, float2& b) {
+    const prc_v4u x = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    a = make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
+    b = make_float2(__uint_as_float(x.z), __uint_as_float(x.w));
+}
 __device__ __forceinline__ void prc_buf_store_c64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float2 v) {
     prc_v2u x;
     x.x = __float_as_uint(v.x);

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_cached_kernel(LsFft
             const __amdgpu_buffer_rsrc_t rc = prc_rsrc(cache + (int64_t)(live ? p : 0) * FFTW_P,
                                                        live ? FFTW_P * 8u : 0u);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rc, vo8, 512u * r);
+            for (int m = 0; m < 8; ++m) prc_buf_load_2c64(rc, (unsigned)lane * 16u, 1024u * m, xn[2 * m], xn[2 * m + 1]);
         }
     };
     issue_x(wg);
@@ -570,7 +570,8 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_cached_kernel(LsFft
             if (a.cache) {
                 float2* __restrict__ cp = cache + (int64_t)p * FFTW_P;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cp[64 * r + lane] = x[r];
+                for (int m = 0; m < 8; ++m)
+                    reinterpret_cast<float4*>(cp)[64 * m + lane] = make_float4(x[2 * m].x, x[2 * m].y, x[2 * m + 1].x, x[2 * m + 1].y);
             }
             fft1024_fwd(up, tile, tab, f);
 #pragma unroll
@@ -672,10 +673,18 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
     auto issue_x = [&](int p) {
         const bool live = p < nblocks;
         if (CACHED) {
+#ifdef LSF_EXP_NOLOAD       // timing ablation only (wrong results): no global loads
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xn[r] = make_float2((float)(lane + p), (float)r);
+            return;
+#endif
             const __amdgpu_buffer_rsrc_t rc = prc_rsrc(cache + (int64_t)(live ? p : 0) * FFTW_P,
                                                        live ? FFTW_P * 8u : 0u);
+            // cache layout [register pair m][lane][2]: registers 2m, 2m+1 of a lane are 16 contiguous bytes (1 KB per
+            // wavefront instruction; measured: the writer 2 % faster, the reader unchanged -- it is bound by the memory
+            // pattern itself, see the ablation in DESIGN.md section 4)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rc, vo8, 512u * r);
+            for (int m = 0; m < 8; ++m) prc_buf_load_2c64(rc, (unsigned)lane * 16u, 1024u * m, xn[2 * m], xn[2 * m + 1]);
         } else {
             const int mstart = (live ? p * B : n) - ext;
             const unsigned voff = vo8 + (unsigned)mstart * 8u;
@@ -713,9 +722,14 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
         __builtin_amdgcn_sched_barrier(0);
         issue_x(p + nwaves);
         {
+#ifdef LSF_EXP_NOLOAD
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = make_float2((float)(lane - n0), (float)(r + cnt));
+#else
             const __amdgpu_buffer_rsrc_t rs = prc_rsrc(srv + n0, lsf_clampu(cnt) * 8u);
 #pragma unroll
             for (int r = 0; r < 16; ++r) sv[r] = prc_buf_load_c64(rs, vslot + 512u * r, 0u);
+#endif
         }
         // one rotation on the way out: from this bin's frame to the frame of whoever reads the stream next
         const bool rot_out = a.rot || a.rot2;
@@ -729,7 +743,9 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
             if (ROT_IN) ibase = make_float2(p1.x, -p1.y);
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifndef LSF_EXP_NOFFT       // timing ablation only (wrong results): no transforms, the memory pattern alone
         fft1024_inv<true>(y, tile, tab, f);
+#endif
         // last `peek` outputs of the block: rho samples whose ramp restarted carry gamma instead of 1
         if (a.rot && peek > 0 && n0 + cnt > n - peek) {
             const float2 g1 = a.gamma_m1;
@@ -771,7 +787,9 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFf
             y[r] = in ? o : make_float2(0.f, 0.f);
         }
         if (a.has_next) {
+#ifndef LSF_EXP_NOFFT
             fft1024_fwd(y, tile, tab, f);
+#endif
 #pragma unroll
             for (int m = 0; m < 16; ++m) cmac_bconj(wrs[m], y[m], xc[m]);
         }
