@@ -622,8 +622,11 @@ __global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_corr_cached_kernel(LsFft
 // per block).  !CACHED (method 2, or when the cache does not fit): it is recomputed from the reference (6 KB per
 // block + L2-served overlap, one more FFT): fewer HBM bytes but a third transform, which makes the kernel
 // VALU-bound -- measured slower than the HBM-bound cached form.
+#ifndef LSF_FUSED_OCC
+#define LSF_FUSED_OCC 2      // wavefronts per SIMD (A/B builds: with the transforms ablated, 3 tells whether more loads in flight help)
+#endif
 template <bool CACHED, bool ROT_IN>
-__global__ __launch_bounds__(64 * LSF_WAVES, 2) void ls_fused_cached_kernel(LsFftArgs a) {
+__global__ __launch_bounds__(64 * LSF_WAVES, LSF_FUSED_OCC) void ls_fused_cached_kernel(LsFftArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
     float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
