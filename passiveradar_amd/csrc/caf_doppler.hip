@@ -40,14 +40,42 @@ __global__ __launch_bounds__(DopCfg<F>::THREADS) void doppler_col_kernel(const f
     for (int r = 0; r < 16; ++r) x[r] = prc_buf_load_c64(ry, ld_thread + cb, (unsigned)(r * Q) * row_bytes);
     const DopTw t = dop_load_twiddles<F>(tw, p);
     dop_stage1<F>(x, t);
-    dop_write1<F>(x, lds, p, c);
-    __syncthreads();
-    dop_read1<F>(x, lds, p, c);
-    dop_stage2<F>(x, t);
-    if (F3 > 1) {
-        dop_write2<F>(x, lds, p, c);      // the slots this thread just read: no barrier in between
+    if (!DopCfg<F>::SPLIT) {
+        dop_write1<F>(x, lds, p, c);
         __syncthreads();
-        dop_read2<F>(x, lds, p, c);
+        dop_read1<F>(x, lds, p, c);
+        dop_stage2<F>(x, t);
+        if (F3 > 1) {
+            dop_write2<F>(x, lds, p, c);      // the slots this thread just read: no barrier in between
+            __syncthreads();
+            dop_read2<F>(x, lds, p, c);
+            dop_stage3<F>(x);
+        }
+    } else {
+        // the same exchanges one component at a time through float slots (half the LDS: two workgroups per CU).  A
+        // read phase is closed by a barrier before the slots are written again; the X2 write of the real parts follows
+        // the X1 read of the imaginary parts directly (own slots, as in the one-round form)
+        float* ldf = reinterpret_cast<float*>(dop_smem);
+        float2 z[16];
+        dop_write1c<F, 0>(x, ldf, p, c);
+        __syncthreads();
+        dop_read1c<F, 0>(z, ldf, p, c);
+        __syncthreads();
+        dop_write1c<F, 1>(x, ldf, p, c);
+        __syncthreads();
+        dop_read1c<F, 1>(z, ldf, p, c);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = z[r];
+        dop_stage2<F>(x, t);
+        dop_write2c<F, 0>(x, ldf, p, c);
+        __syncthreads();
+        dop_read2c<F, 0>(z, ldf, p, c);
+        __syncthreads();
+        dop_write2c<F, 1>(x, ldf, p, c);
+        __syncthreads();
+        dop_read2c<F, 1>(z, ldf, p, c);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = z[r];
         dop_stage3<F>(x);
     }
 #pragma unroll
@@ -68,7 +96,7 @@ bool dop_supported(int F) { return F == 256 || F == 512 || F == 1024 || F == 204
 template <int F>
 static int dop_launch_t(const float2* y, float2* out, const float2* tw, int cols, int nframes, hipStream_t stream) {
     constexpr int KT = DopCfg<F>::KT;
-    const size_t lds = sizeof(float2) * DopCfg<F>::LDS_ELEMS;
+    const size_t lds = DopCfg<F>::LDS_BYTES;
     static bool attr_done[16] = {false};
     int dev = 0;
     PRC_HIP(hipGetDevice(&dev));

@@ -35,8 +35,17 @@ struct DopCfg {
     static constexpr int F3 = F / 256;               // radix of the last stage: 1, 2, 4, 8, 16
     static constexpr int E = 16 / F3;                // last-stage transforms per thread
     static constexpr int KT = F == 256 ? 32 : (F == 512 ? 16 : (F == 1024 ? DOP_KT_1024 : (F == 2048 ? DOP_KT_2048 : 4)));   // columns per workgroup
-    static constexpr int THREADS = Q * KT;           // 512, 512, 1024, 1024, 1024
-    static constexpr int LDS_ELEMS = (F + F / 16) * KT;
+    static constexpr int THREADS = Q * KT;           // 512, 512, 512, 1024, 1024
+    // A tile of more than half a CU's LDS would leave ONE workgroup per CU, its load, exchange and store phases
+    // serialised; such tiles (2048 and 4096 bins) are exchanged in two rounds instead -- real parts, then imaginary parts,
+    // through the same float slots -- so that two workgroups fit a CU and one's memory phase runs under the other's
+    // exchanges (DOP_SPLIT_ABOVE: A/B builds)
+#ifndef DOP_SPLIT_ABOVE
+#define DOP_SPLIT_ABOVE (80 * 1024)
+#endif
+    static constexpr bool SPLIT = (F + F / 16) * KT * 8 > DOP_SPLIT_ABOVE;
+    static constexpr int LDS_ELEMS = (F + F / 16) * KT;                       // float2 (or float, when SPLIT) slots
+    static constexpr int LDS_BYTES = LDS_ELEMS * (SPLIT ? 4 : 8);
 };
 
 PRC_HD int dop_slot(int idx, int kt, int c) { return (idx + (idx >> 4)) * kt + c; }
@@ -137,6 +146,42 @@ PRC_HD void dop_read1(float2 (&x)[16], const float2* lds, int p, int c) {
 #pragma unroll
     for (int a = 0; a < 16; ++a) x[a] = r[(a * F3 + ((a * F3) >> 4)) * KT];
 }
+// the same four accesses on ONE component (C = 0: real, 1: imaginary) through float slots
+template <int F, int C>
+PRC_HD void dop_write1c(const float2 (&x)[16], float* lds, int p, int c) {
+    constexpr int Q = DopCfg<F>::Q, KT = DopCfg<F>::KT;
+    float* w = lds + (p + (p >> 4)) * KT + c;
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) w[k1 * (Q + Q / 16) * KT] = C ? x[k1].y : x[k1].x;
+}
+template <int F, int C>
+PRC_HD void dop_read1c(float2 (&x)[16], const float* lds, int p, int c) {
+    constexpr int KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3;
+    const float* r = lds + dop_base1<F>(p, c);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        const float v = r[(a * F3 + ((a * F3) >> 4)) * KT];
+        if (C) x[a].y = v; else x[a].x = v;
+    }
+}
+template <int F, int C>
+PRC_HD void dop_write2c(const float2 (&x)[16], float* lds, int p, int c) {
+    constexpr int KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3;
+    float* w = lds + dop_base1<F>(p, c);
+#pragma unroll
+    for (int ka = 0; ka < 16; ++ka) w[(ka * F3 + ((ka * F3) >> 4)) * KT] = C ? x[ka].y : x[ka].x;
+}
+template <int F, int C>
+PRC_HD void dop_read2c(float2 (&x)[16], const float* lds, int p, int c) {
+    constexpr int Q = DopCfg<F>::Q, KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3;
+    const float* r = lds + ((p / F3) * (Q + Q / 16) + 17 * (p % F3)) * KT + c;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const float v = r[m * KT];
+        if (C) x[m].y = v; else x[m].x = v;
+    }
+}
+
 template <int F>
 PRC_HD void dop_stage2(float2 (&x)[16], const DopTw& t) {
     dft16<1>(x);

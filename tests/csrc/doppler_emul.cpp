@@ -24,28 +24,65 @@ static int emul(const float2* y, float2* out, int cols, int nframes) {
         for (int k0 = 0; k0 < cols; k0 += KT) {
             for (auto& v : lds) v = make_float2(1e30f, 1e30f);          // a read of an unwritten slot shows
             auto X = [&](int t) -> float2(&)[16] { return *reinterpret_cast<float2(*)[16]>(&regs[(size_t)t * 16]); };
+            if (!DopCfg<F>::SPLIT) {
+                for (int t = 0; t < NT; ++t) {
+                    const int c = t % KT, p = t / KT, k = k0 + c;
+                    float2(&x)[16] = X(t);
+                    for (int r = 0; r < 16; ++r)
+                        x[r] = k < cols ? y[((int64_t)fr * F + r * Q + p) * cols + k] : make_float2(0.f, 0.f);
+                    dop_stage1<F>(x, dop_load_twiddles<F>(tw.data(), p));
+                    dop_write1<F>(x, lds.data(), p, c);
+                }
+                for (int t = 0; t < NT; ++t) {                               // after the first barrier
+                    const int c = t % KT, p = t / KT;
+                    float2(&x)[16] = X(t);
+                    dop_read1<F>(x, lds.data(), p, c);
+                    dop_stage2<F>(x, dop_load_twiddles<F>(tw.data(), p));
+                    if (F3 > 1) dop_write2<F>(x, lds.data(), p, c);           // in place: only slots this thread read
+                }
+                for (int t = 0; t < NT; ++t) {                               // after the second barrier
+                    const int c = t % KT, p = t / KT;
+                    float2(&x)[16] = X(t);
+                    if (F3 > 1) {
+                        dop_read2<F>(x, lds.data(), p, c);
+                        dop_stage3<F>(x);
+                    }
+                }
+            } else {
+                // two-round form: one loop over the threads per barrier-separated phase, float slots
+                float* ldf = reinterpret_cast<float*>(lds.data());
+                std::vector<float2> zreg((size_t)NT * 16);
+                auto Z = [&](int t) -> float2(&)[16] { return *reinterpret_cast<float2(*)[16]>(&zreg[(size_t)t * 16]); };
+                for (int t = 0; t < NT; ++t) {
+                    const int c = t % KT, p = t / KT, k = k0 + c;
+                    float2(&x)[16] = X(t);
+                    for (int r = 0; r < 16; ++r)
+                        x[r] = k < cols ? y[((int64_t)fr * F + r * Q + p) * cols + k] : make_float2(0.f, 0.f);
+                    dop_stage1<F>(x, dop_load_twiddles<F>(tw.data(), p));
+                    dop_write1c<F, 0>(x, ldf, p, c);
+                }
+                for (int t = 0; t < NT; ++t) dop_read1c<F, 0>(Z(t), ldf, t / KT, t % KT);
+                for (int t = 0; t < NT; ++t) dop_write1c<F, 1>(X(t), ldf, t / KT, t % KT);
+                for (int t = 0; t < NT; ++t) {
+                    const int c = t % KT, p = t / KT;
+                    dop_read1c<F, 1>(Z(t), ldf, p, c);
+                    float2(&x)[16] = X(t);
+                    for (int r = 0; r < 16; ++r) x[r] = Z(t)[r];
+                    dop_stage2<F>(x, dop_load_twiddles<F>(tw.data(), p));
+                    dop_write2c<F, 0>(x, ldf, p, c);                          // no barrier: this thread's own slots
+                }
+                for (int t = 0; t < NT; ++t) dop_read2c<F, 0>(Z(t), ldf, t / KT, t % KT);
+                for (int t = 0; t < NT; ++t) dop_write2c<F, 1>(X(t), ldf, t / KT, t % KT);
+                for (int t = 0; t < NT; ++t) {
+                    dop_read2c<F, 1>(Z(t), ldf, t / KT, t % KT);
+                    float2(&x)[16] = X(t);
+                    for (int r = 0; r < 16; ++r) x[r] = Z(t)[r];
+                    dop_stage3<F>(x);
+                }
+            }
             for (int t = 0; t < NT; ++t) {
                 const int c = t % KT, p = t / KT, k = k0 + c;
                 float2(&x)[16] = X(t);
-                for (int r = 0; r < 16; ++r)
-                    x[r] = k < cols ? y[((int64_t)fr * F + r * Q + p) * cols + k] : make_float2(0.f, 0.f);
-                dop_stage1<F>(x, dop_load_twiddles<F>(tw.data(), p));
-                dop_write1<F>(x, lds.data(), p, c);
-            }
-            for (int t = 0; t < NT; ++t) {                               // after the first barrier
-                const int c = t % KT, p = t / KT;
-                float2(&x)[16] = X(t);
-                dop_read1<F>(x, lds.data(), p, c);
-                dop_stage2<F>(x, dop_load_twiddles<F>(tw.data(), p));
-                if (F3 > 1) dop_write2<F>(x, lds.data(), p, c);           // in place: only slots this thread read
-            }
-            for (int t = 0; t < NT; ++t) {                               // after the second barrier
-                const int c = t % KT, p = t / KT, k = k0 + c;
-                float2(&x)[16] = X(t);
-                if (F3 > 1) {
-                    dop_read2<F>(x, lds.data(), p, c);
-                    dop_stage3<F>(x);
-                }
                 if (k < cols)
                     for (int m = 0; m < 16; ++m) {
                         // the kernel splits the row into a per-thread and a per-register part (no carry between them)
