@@ -234,9 +234,8 @@ int caf_launch_fft_team_multi(const CafSegArgs& s, const float2* const* refs, in
     a.segs = total >= 16384 ? 4 : (total >= 4096 ? 2 : 1);
     dim3 grid((unsigned)((s.freq_bins + a.segs - 1) / a.segs), (unsigned)nframes);
     const size_t lds = sizeof(float2) * FT_LDS_ELEMS;
-    PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(s.window ? &caf_fft_team_multi_kernel<true>
-                                                                       : &caf_fft_team_multi_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int rc_ = prc_lds_optin(reinterpret_cast<const void*>(s.window ? &caf_fft_team_multi_kernel<true>
+                                                                       : &caf_fft_team_multi_kernel<false>), (int)lds); if (rc_) return rc_; }
     if (s.window)
         hipLaunchKernelGGL((caf_fft_team_multi_kernel<true>), grid, dim3(FT_THREADS), lds, stream, a);
     else

@@ -41,6 +41,10 @@ void prc_set_error(const char* fmt, ...);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that wants more than 64 KB of LDS: set once per (kernel, device),
+// not on every launch (util.hip)
+int prc_lds_optin(const void* kernel, int bytes);
+
 // ---- device-side complex helpers (float2 = complex64, double2 = complex128) ----
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);

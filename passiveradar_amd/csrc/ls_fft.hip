@@ -883,8 +883,7 @@ int ls_launch_corr_cached(LsFftArgs a, double theta, int waves_per_block, int nb
     if (rc) return rc;
     dim3 grid((unsigned)(waves_per_block / LSF_WAVES), (unsigned)nblocks);
     const size_t lds = sizeof(float2) * (FFTW_TABLE + LSF_WAVES * FFTW_TILE + LSF_WAVES * FFTW_P);
-    PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ls_corr_cached_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    { int rc_ = prc_lds_optin(reinterpret_cast<const void*>(&ls_corr_cached_kernel), 80 * 1024); if (rc_) return rc_; }
     hipLaunchKernelGGL(ls_corr_cached_kernel, grid, dim3(64 * LSF_WAVES), lds, stream, a);
     PRC_LAUNCH_CHECK();
     return PRC_OK;

@@ -211,12 +211,10 @@ int ls_launch_corr_team(LsFftArgs a, double theta, int teams_per_block, int nblo
     dim3 grid((unsigned)teams_per_block, (unsigned)nblocks);
     const size_t lds = sizeof(float2) * FT_LDS_ELEMS;
     if (with_autocorr) {
-        PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ls_corr_team_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_ = prc_lds_optin(reinterpret_cast<const void*>(&ls_corr_team_kernel<true>), (int)lds); if (rc_) return rc_; }
         hipLaunchKernelGGL(ls_corr_team_kernel<true>, grid, dim3(FT_THREADS), lds, stream, a);
     } else {
-        PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ls_corr_team_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { int rc_ = prc_lds_optin(reinterpret_cast<const void*>(&ls_corr_team_kernel<false>), (int)lds); if (rc_) return rc_; }
         hipLaunchKernelGGL(ls_corr_team_kernel<false>, grid, dim3(FT_THREADS), lds, stream, a);
     }
     PRC_LAUNCH_CHECK();
@@ -233,8 +231,7 @@ int ls_launch_fir_team(LsFftArgs a, double theta, int nblocks, hipStream_t strea
     if (teams < 1) teams = 1;
     dim3 grid((unsigned)teams, (unsigned)nblocks);
     const size_t lds = sizeof(float2) * FT_LDS_ELEMS;
-    PRC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ls_fir_team_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { int rc_ = prc_lds_optin(reinterpret_cast<const void*>(&ls_fir_team_kernel), (int)lds); if (rc_) return rc_; }
     hipLaunchKernelGGL(ls_fir_team_kernel, grid, dim3(FT_THREADS), lds, stream, a);
     PRC_LAUNCH_CHECK();
     return PRC_OK;

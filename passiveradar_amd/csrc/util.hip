@@ -11,6 +11,21 @@ void prc_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+#include <set>
+#include <utility>
+int prc_lds_optin(const void* kernel, int bytes) {
+    static std::mutex mtx;
+    static std::set<std::pair<std::pair<const void*, int>, int>> sizes;      // (kernel, device, bytes) already set
+    int dev = 0;
+    PRC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mtx);
+    const auto key = std::make_pair(std::make_pair(kernel, dev), bytes);
+    if (sizes.count(key)) return PRC_OK;
+    PRC_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    sizes.insert(key);
+    return PRC_OK;
+}
+
 extern "C" int prc_version(void) { return PRC_VERSION; }
 
 extern "C" const char* prc_last_error(void) { return g_err; }

@@ -368,3 +368,35 @@ def test_stream_with_the_ls_filter_variant():
         assert rel_err(got[f], exp) < 1e-4, f
     with pytest.raises(ValueError):
         HipBackend(2 * C, R, F, fs, clutter="svd")
+
+
+def test_bench_cfg5_maps_against_single_calls(tmp_path):
+    """bench.py --workload cfg5 (four illuminators against one surveillance channel, full 2048 x 2048 size, one frame):
+    the dumped surfaces equal one fast_xambg call per (reference, surveillance) pair on the regenerated channels --
+    range_doppler_processing.py:12-90 once per pair, which is what a multi-illuminator frame means"""
+    import subprocess
+    import sys
+    import torch
+    from passiveradar_amd.range_doppler_processing import fast_xambg
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    dump = str(tmp_path / "cfg5.npz")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--no-cpu", "--steps", "2", "--warmup", "1",
+                        "--workload", "cfg5", "--frames", "1", "--dump", dump],
+                       capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = np.load(dump)
+    fs, n, R, F, _, _ = bench.WORKLOADS["cfg5"]
+    C = n // 2
+    dev = torch.device("cuda", 0)
+    srv_pad, refs = None, []
+    for i in range(4):                                   # as bench.py builds them (rank 0, frame group 0)
+        r_i, srv_pad = bench.synth_padded(torch, 1, C, fs, R, 777 + 13 * i, dev, add_to=srv_pad)
+        refs.append(r_i)
+    win = torch.from_numpy(np.kaiser(n, 5.0).astype(np.float32)).to(dev)
+    from scipy.signal import get_window
+    win = torch.from_numpy(get_window(("kaiser", 5.0), n).astype(np.float32)).to(dev)
+    for i in range(4):
+        one = fast_xambg(refs[i][:n], srv_pad[:n], R, F, n, win)[:, :, 0].cpu().numpy()
+        assert rel_err(d[f"ill{i}_frames"][0], one) < 1e-6, i
