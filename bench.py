@@ -465,7 +465,7 @@ def main():
         out = outs[0][0]
         s = _lib.torch_stream_ptr()
         e0, e1, e2 = [], [], []
-        for _ in range(reps):
+        for _ in range(reps + 1):                    # the first repetition is a warm-up (dropped); medians below
             a, b, c = ev(), ev(), ev()
             a.record()
             be.caf.execute_segments(ref0[first:], clean[first:], nb, C, n, be.window, s)
@@ -474,22 +474,23 @@ def main():
             c.record()
             e0.append(a); e1.append(b); e2.append(c)
         torch.cuda.synchronize()
-        kt["caf_segments"] = {"ms": float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)])),
+        e0, e1, e2 = e0[1:], e1[1:], e2[1:]
+        kt["caf_segments"] = {"ms": float(np.median([a.elapsed_time(b) for a, b in zip(e0, e1)])),
                               "launches_per_step": -(-nframes // batch) * len(refs), "bound": "hbm",
                               "work": nb * (20.0 * n + 8.0 * F * (R + 1))}
-        kt["caf_doppler"] = {"ms": float(np.mean([b.elapsed_time(c) for b, c in zip(e1, e2)])),
+        kt["caf_doppler"] = {"ms": float(np.median([b.elapsed_time(c) for b, c in zip(e1, e2)])),
                              "launches_per_step": -(-nframes // batch) * len(refs), "bound": "hbm",
                              "work": nb * 16.0 * F * (R + 1)}
         if clutter == "ls":
             be.ls.set_profiling(True)
             nb_ls = min(nlocal, be.sub)                         # blocks behind one LS launch
-            acc = np.zeros(3)
-            for _ in range(reps):
+            samples = []
+            for _ in range(reps + 1):                # first repetition: warm-up, dropped
                 be._clean_range(ref0, srv_pad, clean, 0, nb_ls, s)
                 ms3, k3 = be.ls.get_profile()
-                acc += ms3
+                samples.append(ms3)
             be.ls.set_profiling(False)
-            acc /= reps
+            acc = np.median(np.array(samples[1:]), axis=0)     # median per kernel kind: one disturbed repetition does not count
             T = R + 10
             fused = k3[0] == 1 and k3[2] > 1                   # cached-spectrum chain: corr(i+1) inside FIR(i)
             execs = -(-nlocal // nb_ls)                        # LS executes per step

@@ -34,6 +34,7 @@ pmc() {   # pmc <name> <bench args...>: one pass per counter group
 }
 # 1. the bench lines of record (default with the CPU leg and the as-is figure; the other configs with their CPU legs)
 run bench_default $B --cpu-asis
+run bench_default_allcores $B --steps 5 --cpu-workers all
 run bench_cfg3 $B --workload cfg3
 run bench_cfg4 $B --workload cfg4 --no-cpu
 run bench_cfg5 $B --workload cfg5

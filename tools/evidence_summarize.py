@@ -33,7 +33,7 @@ def cmd(name):
 
 
 # ---- bench lines ---------------------------------------------------------------------------------------------------
-for name in ("bench_default", "bench_cfg3", "bench_cfg4", "bench_cfg5"):
+for name in ("bench_default", "bench_default_allcores", "bench_cfg3", "bench_cfg4", "bench_cfg5"):
     d = load_line(name)
     if d:
         json.dump(d, open(os.path.join(S, f"{tag}_{name}.json"), "w"), indent=1)
