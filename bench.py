@@ -189,7 +189,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--sub-batch", type=int, default=SUB_BATCH, help="frames per CAF launch and per gather")
     ap.add_argument("--caf-method", type=int, default=0, help="0 auto, 1 direct, 2 fft")
-    ap.add_argument("--ls-method", type=int, default=0, help="0 auto, 1 time-domain, 2 FFT, 3 FFT + spectrum cache")
+    ap.add_argument("--ls-method", type=int, default=0, help="0 auto, 1 time-domain, 2 FFT, 3 FFT + spectrum cache, 4 = 3 on 4096-point transforms")
     ap.add_argument("--nsub", type=int, default=1, help="LS sub-batches per CAF sub-batch when stages are pipelined")
     ap.add_argument("--ls-streams", type=int, default=3, help="LS chains in flight (alternate sub-batches on separate streams)")
     ap.add_argument("--no-overlap", action="store_true",

@@ -130,7 +130,9 @@ typedef struct prc_ls_desc {
     int32_t max_blocks;    /* workspace is sized for this many independent blocks           */
     int32_t method;        /* 0 auto (= 3 when it fits), 1 time-domain kernels, 2 FFT kernels that
                               recompute the reference spectra per Doppler bin, 3 FFT kernels with
-                              the reference spectra cached in HBM between Doppler bins.  The FFT
+                              the reference spectra cached in HBM between Doppler bins, 4 the chain
+                              of method 3 on 4096-point transforms where it applies (linear form,
+                              <= 769 taps, n >= 8192: fewer cache bytes per sample; else as 3).  The FFT
                               kernels take up to 769 taps on 1024-point transforms (one wavefront
                               each) and up to 3073 taps on 4096-point transforms (four wavefronts).
                               LIMIT: filter_len + peek <= 3413 taps for every method (the Levinson

@@ -815,7 +815,8 @@ struct prc_ls_plan {
     int nblk;          // partial-sum slots per block (tiles of the direct kernel / waves of the FFT kernel)
     int method;        // 1 time-domain, 2 FFT
     int fft_waves;     // waves (1024-point kernels) or teams (4096-point kernels) per block in the FFT correlation kernel
-    bool team = false; // 770 .. 3073 taps: the 4096-point team kernels of ls_fft_team.hip
+    bool team = false; // the 4096-point team kernels of ls_fft_team.hip (770 .. 3073 taps, or method 4)
+    bool team_chain = false;   // cached-spectrum chain on the 4096-point transform (ls_fft_team_cached.hip)
     float2* d_partial = nullptr;
     double2* d_taps = nullptr;
     double2* d_rhs = nullptr;      // right-hand sides of the per-bin Levinson solve, [block][T] (one element read per step)
@@ -865,7 +866,7 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     PRC_REQUIRE(plan && d, PRC_EINVAL, "prc_ls_plan_create: null argument");
     PRC_REQUIRE(d->n > 0 && d->filter_len > 0 && d->peek >= 0 && d->max_blocks > 0, PRC_EINVAL,
                 "prc_ls_plan_create: non-positive size");
-    PRC_REQUIRE(d->method >= 0 && d->method <= 3, PRC_EINVAL, "prc_ls_plan_create: method %d", d->method);
+    PRC_REQUIRE(d->method >= 0 && d->method <= 4, PRC_EINVAL, "prc_ls_plan_create: method %d", d->method);
     const int T = d->filter_len + d->peek;
     PRC_REQUIRE(T < d->n, PRC_EINVAL, "prc_ls_plan_create: filter_len+peek (%d) >= n (%lld)", T,
                 (long long)d->n);
@@ -877,6 +878,10 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     p->method = d->method;
     if (p->method == 0) p->method = (ls_fft_supported(T) || ls_team_supported(T)) ? 2 : 1;
     if (p->method == 3) p->method = 2;          // same kernels; d->method == 3 only adds the spectrum cache
+    if (p->method == 4) {                       // the chain of method 3 on 4096-point transforms, where it applies
+        p->method = 2;
+        if (!d->circular && ls_fft_supported(T) && d->n >= 2 * 4096) p->team = p->team_chain = true;
+    }
     if (p->method == 2 && !ls_fft_supported(T)) {
         if (!ls_team_supported(T)) {
             prc_set_error("prc_ls_plan_create: FFT method supports at most 3073 taps, got %d", T);
@@ -892,7 +897,7 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     if (e == hipSuccess) e = hipMalloc(&p->d_rhs, sizeof(double2) * (size_t)d->max_blocks * T);
     if (e == hipSuccess) e = hipMalloc(&p->d_tmp[0], sizeof(float2) * (size_t)d->max_blocks * d->n);
     if (e == hipSuccess) e = hipMalloc(&p->d_tmp[1], sizeof(float2) * (size_t)d->max_blocks * d->n);
-    if (e == hipSuccess && p->method == 2 && !d->circular && !p->team) {
+    if (e == hipSuccess && p->method == 2 && !d->circular && (!p->team || p->team_chain)) {
         e = hipMalloc(&p->d_c0, sizeof(double2) * (size_t)d->max_blocks * T);
         if (e == hipSuccess) e = hipMalloc(&p->d_se, sizeof(double2) * (size_t)d->max_blocks * T);
         p->chain = true;
@@ -920,9 +925,11 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
         // bin (measured: the fused kernel is HBM-bound at 2 FFTs per block and VALU-bound at 3).  If the
         // cache does not fit, the chain silently recomputes.
         if (e == hipSuccess && d->method != 2) {
-            if (hipMalloc(&p->d_cache, sizeof(float2) * (size_t)d->max_blocks * ls_cache_elems_per_block(d->n, T)) != hipSuccess) {
+            const int64_t per_block = p->team_chain ? ls_team_cache_elems_per_block(d->n, T) : ls_cache_elems_per_block(d->n, T);
+            if (hipMalloc(&p->d_cache, sizeof(float2) * (size_t)d->max_blocks * per_block) != hipSuccess) {
                 p->d_cache = nullptr;
                 (void)hipGetLastError();
+                if (p->team_chain) p->chain = false;    // the 4096-point chain has no recomputing form: per-bin kernels then
             }
         }
         if (e == hipSuccess)
@@ -1030,7 +1037,8 @@ static int run_cached_chain(prc_ls_plan* p, const void* ref, const void* srv, in
         LsFftArgs xa;
         fill_xa(xa, p, ref, stride, cur, cur_stride, nullptr, 0, pr0);
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[0], stream));
-        rc = ls_launch_corr_cached(xa, theta_exact(0), p->fft_waves, nblocks, stream);
+        rc = p->team_chain ? ls_launch_corr_cached_team(xa, theta_exact(0), p->fft_waves, nblocks, stream)
+                           : ls_launch_corr_cached(xa, theta_exact(0), p->fft_waves, nblocks, stream);
         if (rc) return rc;
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[1], stream));
         LsPrepArgs pa;
@@ -1064,8 +1072,10 @@ static int run_cached_chain(prc_ls_plan* p, const void* ref, const void* srv, in
         }
         const double theta_eff = pr.enabled ? (double)pr.a32 * (double)pr.rcp32 : 0.0;
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
-        rc = ls_launch_fused_cached(xa, theta_exact(ib), theta_out, -theta_eff * (double)n, p->fft_waves,
-                                    nblocks, stream);
+        rc = p->team_chain ? ls_launch_fused_cached_team(xa, theta_exact(ib), theta_out, -theta_eff * (double)n,
+                                                         p->fft_waves, nblocks, stream)
+                           : ls_launch_fused_cached(xa, theta_exact(ib), theta_out, -theta_eff * (double)n, p->fft_waves,
+                                                    nblocks, stream);
         if (rc) return rc;
         if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 3], stream));
         cur = dst;

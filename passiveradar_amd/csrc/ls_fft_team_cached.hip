@@ -1,0 +1,362 @@
+// Cached-spectrum chain of LS_Filter_Multiple (clutter_removal.py:162-187) on the 4096-point team transform.
+//
+// Same algebra and the same edge handling as ls_corr_cached_kernel / ls_fused_cached_kernel of ls_fft.hip (read the
+// comment block there first); the only change is the transform length.  Why it pays: both kernels are bound by HBM
+// traffic, and the spectrum cache costs P complex64 per piece of P - (T-1) new samples.  For the T = 266 taps of the
+// headline configuration that is 8192 B / 759 samples = 10.8 B per sample with P = 1024 and 32768 B / 3831 samples
+// = 8.6 B per sample with P = 4096, next to the 16 B per sample of reading the stream and writing it back.
+//
+// One workgroup (four wavefronts, fft_team.h) per piece.  Slot idx = 256 r + t of a piece at n0 holds rho[n0 - ext + idx]
+// for the block spectrum X_p and the (surveillance / cleaned) sample n0 + idx - ext in slots [ext, ext + cnt) for the
+// correlation inputs.  Compiled with one exchange buffer (FT_NBUF = 1, Makefile): 36 KB of exchange + 32 KB of
+// per-thread spectrum (autocorrelation accumulator / tap spectrum) = 68 KB per workgroup, two workgroups per CU.
+#include "ls_internal.h"
+#include "fft_team.h"
+#include <math.h>
+
+#define LTC_SPEC FT_P                        // float2 of per-thread spectrum kept in LDS behind the transform's area
+
+__device__ __forceinline__ unsigned ltc_clampu(int x) { return x < 0 ? 0u : (unsigned)x; }
+
+__device__ __forceinline__ void ltc_cmac_bconj(float2& w, float2 u, float2 x) {   // w += u * conj(x)
+    w.x = fmaf(u.x, x.x, w.x);
+    w.x = fmaf(u.y, x.y, w.x);
+    w.y = fmaf(u.y, x.x, w.y);
+    w.y = fmaf(-u.x, x.y, w.y);
+}
+
+// First bin of the chain: X_p = FFT(rho block p) -> spectrum cache; partial sums of the autocorrelation of rho and of
+// the cross-correlation with the rotated surveillance stream (three forward transforms per piece).
+__global__ __launch_bounds__(FT_THREADS, 2) void ls_corr_cached_team_kernel(LsFftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    const FtLane f = ft_setup(lds, a.tab);
+    const int t = f.t;
+    const int team = blockIdx.x, nteams = gridDim.x;
+    const int b = blockIdx.y;
+    const float2* __restrict__ ref = a.ref + (int64_t)b * a.ref_stride;
+    const float2* __restrict__ srv = a.srv + (int64_t)b * a.srv_stride;
+    const int n = (int)a.n;
+    const int T = a.T, B = a.piece, ext = T - 1, peek = a.peek;
+    const int npieces = (n + B - 1) / B;
+    float2* __restrict__ cache = a.cache + (int64_t)b * npieces * FT_P;
+    const unsigned vo8 = (unsigned)t * 8u;
+    const unsigned vslot = vo8 - (unsigned)ext * 8u;          // slot idx -> piece sample idx-ext (idx<ext: out of range)
+    const __amdgpu_buffer_rsrc_t rx = prc_rsrc(ref + peek, ltc_clampu(n - peek) * 8u);
+
+    // autocorrelation accumulator: element (r, t) is private to thread t, it only lives in LDS to save 32 VGPRs
+    float2* Wrr = lds + FT_LDS_ELEMS + t;
+    float2 wrs[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) { Wrr[FT_THREADS * m] = make_float2(0.f, 0.f); wrs[m] = make_float2(0.f, 0.f); }
+
+    float2 xn[16];                                            // block of the next piece (prefetched)
+    auto issue_x = [&](int p) {
+        const bool live = p < npieces;
+        const int mstart = (live ? p * B : n) - ext;          // dead prefetch: everything out of range
+        const unsigned voff = vo8 + (unsigned)mstart * 8u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rx, voff + 2048u * r, 0u);
+    };
+    issue_x(team);
+    for (int p = team; p < npieces; p += nteams) {
+        const int n0 = p * B;
+        const int cnt = (n - n0) < B ? (n - n0) : B;
+        const int mstart = n0 - ext;
+        float2 x[16], u[16], up[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = xn[r];
+        // surveillance piece in slots [ext, ext+cnt), rotated below by e^{-j theta (n+peek)}
+        {
+            const __amdgpu_buffer_rsrc_t rs = prc_rsrc(srv + n0, ltc_clampu(cnt) * 8u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = prc_buf_load_c64(rs, vslot + 2048u * r, 0u);
+        }
+        float2 sbase = make_float2(1.f, 0.f);
+        if (a.rot) {
+            sbase = phase_rot(a.pr, (int64_t)mstart + t + peek);
+            sbase.y = -sbase.y;
+        }
+        // wrapped tail of rho (source index restarts at ref[0]); unrotated, so no phase here
+        const int wstart = n - peek - mstart;
+        if (peek > 0 && wstart < FT_P) {
+            int cw = FT_P - wstart;
+            if (cw > peek) cw = peek;
+            const __amdgpu_buffer_rsrc_t rw = prc_rsrc(ref, ltc_clampu(cw) * 8u);
+            const unsigned voff = vo8 - (unsigned)wstart * 8u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float2 w = prc_buf_load_c64(rw, voff + 2048u * r, 0u);
+                x[r].x += w.x;
+                x[r].y += w.y;
+            }
+        }
+        // rho piece in slots [ext, ext+cnt): the same samples, masked by the range check
+        {
+            int cu = cnt;
+            if (n - peek - n0 < cu) cu = n - peek - n0;
+            const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + peek + n0, ltc_clampu(cu) * 8u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) up[r] = prc_buf_load_c64(ru, vslot + 2048u * r, 0u);
+            const int wst = n - peek - n0;                    // first wrapped sample of the piece
+            if (peek > 0 && wst < cnt) {
+                // a last piece shorter than peek starts inside the wrapped run (wst < 0): its source starts at ref[-wst]
+                const int w0 = wst > 0 ? wst : 0;
+                const __amdgpu_buffer_rsrc_t rw = prc_rsrc(ref + (w0 - wst), ltc_clampu(cnt - w0) * 8u);
+                const unsigned voff = vslot - (unsigned)w0 * 8u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float2 w = prc_buf_load_c64(rw, voff + 2048u * r, 0u);
+                    up[r].x += w.x;
+                    up[r].y += w.y;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ft4096_fwd<0>(x, f);
+        {
+            // cache layout [register pair m][t][2]: registers 2m, 2m+1 of a thread are 16 contiguous bytes
+            float4* __restrict__ cp = reinterpret_cast<float4*>(cache + (int64_t)p * FT_P);
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                cp[FT_THREADS * m + t] = make_float4(x[2 * m].x, x[2 * m].y, x[2 * m + 1].x, x[2 * m + 1].y);
+        }
+        ft4096_fwd<1>(up, f);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            float2 w = Wrr[FT_THREADS * m];
+            ltc_cmac_bconj(w, up[m], x[m]);
+            Wrr[FT_THREADS * m] = w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (a.rot) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float2 st = a.step[r];
+                st.y = -st.y;
+                u[r] = cmul(u[r], cmul(sbase, st));
+            }
+        }
+        issue_x(p + nteams);
+        __builtin_amdgcn_sched_barrier(0);
+        ft4096_fwd<0>(u, f);
+        ft_team_sync();                                       // three transforms per piece: the next piece starts at buffer 0 again
+#pragma unroll
+        for (int m = 0; m < 16; ++m) ltc_cmac_bconj(wrs[m], u[m], x[m]);
+    }
+    ft4096_inv<0>(wrs, f);
+    float2 wrr[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wrr[m] = Wrr[FT_THREADS * m];
+    ft4096_inv<1>(wrr, f);
+    // partial[b][team][0/1][lag] holds conj(g): the prepare / solve prologues conjugate back
+    float2* __restrict__ part = a.partial + ((int64_t)b * nteams + team) * 2 * T;
+    const float sc = 1.0f / (float)FT_P;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int lag = FT_THREADS * r + t;
+        if (lag < T) {
+            part[lag] = make_float2(wrr[r].x * sc, -wrr[r].y * sc);
+            part[T + lag] = make_float2(wrs[r].x * sc, -wrs[r].y * sc);
+        }
+    }
+}
+
+// FIR of bin i fused with the cross-correlation of bin i+1: per piece the team reads X_p (cache, 32 KB) and the
+// surveillance piece once, writes the cleaned piece once and keeps it in registers as the next bin's correlation input
+// (one inverse and one forward transform per piece).
+template <bool ROT_IN>
+__global__ __launch_bounds__(FT_THREADS, 2) void ls_fused_cached_team_kernel(LsFftArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    const FtLane f = ft_setup(lds, a.tab);
+    const int t = f.t;
+    const int team = blockIdx.x, nteams = gridDim.x;
+    const int b = blockIdx.y;
+    const float2* __restrict__ ref = a.ref + (int64_t)b * a.ref_stride;
+    const float2* __restrict__ srv = a.srv + (int64_t)b * a.srv_stride;
+    float2* __restrict__ out = a.out + (int64_t)b * a.out_stride;
+    const double2* __restrict__ taps = a.taps_t + (int64_t)b * a.T;
+    const int n = (int)a.n;
+    const int T = a.T, B = a.piece, ext = T - 1, peek = a.peek;
+    const int nblocks = (n + B - 1) / B;
+    const float2* __restrict__ cache = a.cache + (int64_t)b * nblocks * FT_P;
+    const unsigned vo8 = (unsigned)t * 8u;
+    const unsigned vslot = vo8 - (unsigned)ext * 8u;
+
+    // H~ = FFT(taps) / 4096 of this block (frequency layout); element (r, t) is private to thread t and parked in LDS
+    float2* Hs = lds + FT_LDS_ELEMS + t;
+    const float sc = 1.0f / (float)FT_P;
+    {
+        float2 h[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = FT_THREADS * r + t;
+            const double2 tp = taps[idx < T ? idx : 0];
+            h[r] = idx < T ? make_float2((float)tp.x, (float)tp.y) : make_float2(0.f, 0.f);
+        }
+        ft4096_fwd<1>(h, f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Hs[FT_THREADS * r] = make_float2(h[r].x * sc, h[r].y * sc);
+    }
+
+    float2 wrs[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wrs[m] = make_float2(0.f, 0.f);
+
+    float2 xn[16];
+    auto issue_x = [&](int p) {
+        const bool live = p < nblocks;
+#ifdef LTC_EXP_NOLOAD       // timing ablation only (wrong results): no global loads
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xn[r] = make_float2((float)(t + p), (float)r);
+        return;
+#endif
+        const __amdgpu_buffer_rsrc_t rc = prc_rsrc(cache + (int64_t)(live ? p : 0) * FT_P, live ? FT_P * 8u : 0u);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) prc_buf_load_2c64(rc, (unsigned)t * 16u, 4096u * m, xn[2 * m], xn[2 * m + 1]);
+    };
+    issue_x(team);
+    for (int p = team; p < nblocks; p += nteams) {
+        const int n0 = p * B;
+        const int cnt = (n - n0) < B ? (n - n0) : B;
+        float2 xc[16], y[16], sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xc[r] = xn[r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = cmul(xc[r], Hs[FT_THREADS * r]);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(p + nteams);
+        {
+#ifdef LTC_EXP_NOLOAD
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = make_float2((float)(t - n0), (float)(r + cnt));
+#else
+            const __amdgpu_buffer_rsrc_t rs = prc_rsrc(srv + n0, ltc_clampu(cnt) * 8u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = prc_buf_load_c64(rs, vslot + 2048u * r, 0u);
+#endif
+        }
+        // one rotation on the way out: from this bin's frame to the frame of whoever reads the stream next
+        const bool rot_out = a.rot || a.rot2;
+        float2 obase = make_float2(1.f, 0.f), ibase = make_float2(1.f, 0.f);
+        if (rot_out) {
+            const int64_t idx = (int64_t)n0 - ext + t + peek;
+            const float2 p1 = a.rot ? phase_rot(a.pr, idx) : make_float2(1.f, 0.f);
+            float2 p2 = a.rot2 ? phase_rot(a.pr2, idx) : make_float2(1.f, 0.f);
+            p2.y = -p2.y;
+            obase = cmul(p1, p2);
+            if (ROT_IN) ibase = make_float2(p1.x, -p1.y);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef LTC_EXP_NOFFT       // timing ablation only (wrong results): no transforms, the memory pattern alone
+        ft4096_inv<0>(y, f);
+#endif
+        // last `peek` outputs of the block: rho samples whose ramp restarted carry gamma instead of 1
+        if (a.rot && peek > 0 && n0 + cnt > n - peek) {
+            const float2 g1 = a.gamma_m1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = n0 + FT_THREADS * r + t - ext;
+                const int over = nn - (n - peek);            // 0..peek-1 for affected outputs
+                if (over >= 0 && nn < n) {
+                    float2 acc = make_float2(0.f, 0.f);
+                    for (int k = 0; k <= over && k < T; ++k) {
+                        const double2 wk = taps[k];
+                        cmac(acc, make_float2((float)wk.x, (float)wk.y), ref[over - k]);   // rho[nn-k] = ref[nn-k+peek-n]
+                    }
+                    const float2 c = cmul(g1, acc);
+                    y[r].x += c.x;
+                    y[r].y += c.y;
+                }
+            }
+        }
+        const __amdgpu_buffer_rsrc_t ro = prc_rsrc(out + n0, ltc_clampu(cnt) * 8u);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float2 sin_ = sv[r];
+            if (ROT_IN) {                                   // raw input, rotated bin: s~ = s e^{-j phi_i}
+                float2 st = a.step2[r];
+                st.y = -st.y;
+                sin_ = cmul(sin_, cmul(ibase, st));
+            }
+            float2 o = make_float2(sin_.x - y[r].x, sin_.y - y[r].y);
+            if (rot_out) o = cmul(o, cmul(obase, a.step[r]));
+            prc_buf_store_c64(ro, vslot + 2048u * r, 0u, o);
+            // the stored piece (already in the next bin's frame) stays in registers as that bin's correlation
+            // input: slots [ext, ext+cnt) only (the other slots of y are circular-convolution garbage)
+            const int idx = FT_THREADS * r + t;
+            const bool in = idx >= ext && idx < ext + cnt;
+            y[r] = in ? o : make_float2(0.f, 0.f);
+        }
+        if (a.has_next) {
+#ifndef LTC_EXP_NOFFT
+            ft4096_fwd<1>(y, f);
+#endif
+#pragma unroll
+            for (int m = 0; m < 16; ++m) ltc_cmac_bconj(wrs[m], y[m], xc[m]);
+        }
+    }
+    if (a.has_next) {
+        ft4096_inv<0>(wrs, f);
+        float2* __restrict__ part = a.partial + ((int64_t)b * nteams + team) * 2 * T;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lag = FT_THREADS * r + t;
+            if (lag < T) part[T + lag] = make_float2(wrs[r].x * sc, -wrs[r].y * sc);
+        }
+    }
+}
+
+int64_t ls_team_cache_elems_per_block(int64_t n, int T) {
+    const int64_t B = FT_P - (T - 1);
+    return ((n + B - 1) / B) * FT_P;
+}
+
+static void ltc_fill(LsFftArgs& a, double theta) {
+    a.piece = FT_P - (a.T - 1);
+    a.theta32 = (float)theta;
+    for (int r = 0; r < 16; ++r) {
+        const double ang = theta * (double)FT_THREADS * r;
+        a.step[r] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+}
+
+static constexpr size_t LTC_LDS = sizeof(float2) * (FT_LDS_ELEMS + LTC_SPEC);
+
+int ls_launch_corr_cached_team(LsFftArgs a, double theta, int teams_per_block, int nblocks, hipStream_t stream) {
+    ltc_fill(a, theta);
+    int rc = ft_device_tables(&a.tab);
+    if (rc) return rc;
+    rc = prc_lds_optin(reinterpret_cast<const void*>(&ls_corr_cached_team_kernel), (int)LTC_LDS);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ls_corr_cached_team_kernel, dim3((unsigned)teams_per_block, (unsigned)nblocks), dim3(FT_THREADS),
+                       LTC_LDS, stream, a);
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}
+
+int ls_launch_fused_cached_team(LsFftArgs a, double theta, double theta_out, double gamma_angle, int teams_per_block,
+                                int nblocks, hipStream_t stream) {
+    ltc_fill(a, theta);
+    for (int r = 0; r < 16; ++r) {
+        const double ang_in = theta * (double)FT_THREADS * r, ang = (theta - theta_out) * (double)FT_THREADS * r;
+        a.step2[r] = make_float2((float)cos(ang_in), (float)sin(ang_in));
+        a.step[r] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    a.gamma_m1 = make_float2((float)(cos(gamma_angle) - 1.0), (float)sin(gamma_angle));
+    int rc = ft_device_tables(&a.tab);
+    if (rc) return rc;
+    const dim3 grid((unsigned)teams_per_block, (unsigned)nblocks), block(FT_THREADS);
+    if (a.rot_in) {
+        rc = prc_lds_optin(reinterpret_cast<const void*>(&ls_fused_cached_team_kernel<true>), (int)LTC_LDS);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ls_fused_cached_team_kernel<true>, grid, block, LTC_LDS, stream, a);
+    } else {
+        rc = prc_lds_optin(reinterpret_cast<const void*>(&ls_fused_cached_team_kernel<false>), (int)LTC_LDS);
+        if (rc) return rc;
+        hipLaunchKernelGGL(ls_fused_cached_team_kernel<false>, grid, block, LTC_LDS, stream, a);
+    }
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}

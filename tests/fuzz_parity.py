@@ -10,7 +10,10 @@ from passiveradar_amd.range_doppler_processing import fast_xambg, fast_xambg_mul
 from passiveradar_amd.signal_utils import decimate_iir, deinterleave_IQ, find_channel_offset, frequency_shift, front_end, resample, xcorr
 from passiveradar_amd.target_detection import CFAR_2D
 
-import threading
+import os, threading
+from passiveradar_amd import clutter_removal as _cr
+_cr.set_default_ls_method(int(os.environ.get("PR_FUZZ_LS_METHOD", "0")))      # e.g. 4: the LS kinds on the 4096-point chain
+KINDS = [int(x) for x in os.environ["PR_FUZZ_KINDS"].split(",")] if os.environ.get("PR_FUZZ_KINDS") else None
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 90.0
 nthreads = int(sys.argv[3]) if len(sys.argv) > 3 else 1        # dask-style concurrent callers
@@ -31,7 +34,7 @@ def note(kind, err, tol, desc):
 def worker(wseed):
   rng = np.random.default_rng(wseed)
   while time.time() - t0 < budget:
-      k = rng.integers(0, 22)
+      k = rng.integers(0, 22) if KINDS is None else int(rng.choice(KINDS))
       if k == 20:     # power-of-two Doppler bin counts: the column-FFT Doppler kernel (256 .. 4096), ragged column tiles
           F = int(rng.choice([256, 512, 1024, 2048, 4096])); q = int(rng.integers(4, 40)); N = F * q + int(rng.integers(0, F))
           R = int(rng.integers(1, min(700, N // 2 - 1)))

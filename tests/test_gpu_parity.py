@@ -77,12 +77,12 @@ def test_caf_cfg3_digest():
     assert np.abs(out.sum(axis=1) - g["row_sums"]).max() / (peak * np.sqrt(R + 1)) < TOL
 
 
-@pytest.fixture(params=["direct", "fft", "fft_cached"])
+@pytest.fixture(params=["direct", "fft", "fft_cached", "fft4096_cached"])
 def ls_method(request):
     """run every LS case through every kernel family (time-domain LDS tiles / wavefront FFT with the
-    reference spectra recomputed per bin / kept in an HBM cache)"""
+    reference spectra recomputed per bin / kept in an HBM cache / the cached chain on 4096-point team transforms)"""
     from passiveradar_amd import clutter_removal as cr
-    cr.set_default_ls_method({"direct": 1, "fft": 2, "fft_cached": 3}[request.param])
+    cr.set_default_ls_method({"direct": 1, "fft": 2, "fft_cached": 3, "fft4096_cached": 4}[request.param])
     yield request.param
     cr.set_default_ls_method(0)
 
@@ -360,6 +360,25 @@ def test_ls_chain_last_piece_shorter_than_peek(tail):
         assert rel_err(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)) < 5e-6, bins
 
 
+@pytest.mark.parametrize("tail", [1, 5, 10, 2000])
+def test_ls_team_chain_last_piece_shorter_than_peek(tail):
+    """the same edge on the 4096-point chain (method 4): six pieces of 4097 - T samples + `tail`; also peek = 0 and a
+    single-bin call (per-bin team kernels) on the same plan family"""
+    from passiveradar_amd import clutter_removal as cr
+    L, fs = 48, 1.0e4
+    n = 6 * (4097 - (L + 10)) + tail
+    ref, srv = scene.make_scene(n, fs, 50, 54321)
+    cr.set_default_ls_method(4)
+    try:
+        for bins in ([0, 0], [0, 2], [2, 0, -1], [0]):
+            assert rel_err(cr.LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)) < 5e-6, bins
+        got, taps = cr.LS_Filter_Toeplitz(ref, srv, L, 0, True)
+        exp, etaps = O.LS_Filter_Toeplitz(ref, srv, L, 0, True)
+        assert rel_err(got, exp) < TIGHT and rel_err(taps, etaps) < TIGHT
+    finally:
+        cr.set_default_ls_method(0)
+
+
 def test_library_first_then_torch_in_a_fresh_process():
     """import order must not matter: libprcore used before torch is imported (fresh interpreter), then torch must
     still see the GPU and the device-tensor path must agree with the NumPy path (one HIP runtime per process)"""
@@ -496,7 +515,7 @@ def test_ls_far_bins_long_block_chain():
     ref, srv = scene.make_scene(n, fs, L, 2718)
     bins = [0.0, 300.0, -450.0, 2.0]
     exp = O.LS_Filter_Multiple(ref, srv, L, fs, bins)
-    for m in (0, 1, 2, 3):
+    for m in (0, 1, 2, 3, 4):
         cr.set_default_ls_method(m)
         try:
             out = cr.LS_Filter_Multiple(ref, srv, L, fs, bins)
