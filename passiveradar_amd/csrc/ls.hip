@@ -878,9 +878,14 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     p->method = d->method;
     if (p->method == 0) p->method = (ls_fft_supported(T) || ls_team_supported(T)) ? 2 : 1;
     if (p->method == 3) p->method = 2;          // same kernels; d->method == 3 only adds the spectrum cache
-    if (p->method == 4) {                       // the chain of method 3 on 4096-point transforms, where it applies
-        p->method = 2;
-        if (!d->circular && ls_fft_supported(T) && d->n >= 2 * 4096) p->team = p->team_chain = true;
+    // The cached-spectrum chain on 4096-point transforms (method 4; AUTO from 250 taps on blocks of >= 16 pieces): the
+    // spectrum cache costs 32768 / (4097 - T) bytes per sample instead of 8192 / (1025 - T).  Measured on the five-bin
+    // chain at 256 chunks of 1.2 M samples (tools/ls_chain_bench.py): T = 64 / 128 / 192 / 256 / 266 / 384 / 512 / 768
+    // -> 1.06 / 1.04 / 1.01 / 0.99 / 0.96 / 0.92 / 0.81 / 0.54 of the 1024-point chain's time.
+    const bool team_chain_ok = !d->circular && ls_fft_supported(T) && d->n >= 2 * 4096;
+    if (d->method == 4 || (d->method == 0 && T >= 250 && d->n >= 16 * 4096)) {
+        if (p->method == 4) p->method = 2;
+        if (team_chain_ok) p->team = p->team_chain = true;
     }
     if (p->method == 2 && !ls_fft_supported(T)) {
         if (!ls_team_supported(T)) {
@@ -890,7 +895,8 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
         }
         p->team = true;                         // beyond the 1024-point transform: 4096-point team kernels
     }
-    p->fft_waves = p->team ? ls_team_teams_per_block(d->n, T) : ls_fft_waves_per_block(d->n, T);
+    p->fft_waves = p->team_chain ? ls_team_chain_teams_per_block(d->n, T, d->max_blocks)
+                   : p->team     ? ls_team_teams_per_block(d->n, T) : ls_fft_waves_per_block(d->n, T);
     p->nblk = p->method == 2 ? p->fft_waves : (int)ceil_div64(d->n, LSC_BLK);
     hipError_t e = hipMalloc(&p->d_partial, sizeof(float2) * (size_t)d->max_blocks * p->nblk * 2 * T);
     if (e == hipSuccess) e = hipMalloc(&p->d_taps, sizeof(double2) * (size_t)d->max_blocks * T);
