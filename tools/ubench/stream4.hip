@@ -15,13 +15,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* base, unsigne
     return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-template <int LDC, int LDS_, int ST>
+// MODE 0: team i takes pieces i, i + nteams, ... (the kernel's order); 1: team i takes a contiguous run of pieces;
+// 2: as 0 with the chunk index fastest in the grid (x = chunk, y = team)
+template <int LDC, int LDS_, int ST, bool WAIT_FIRST = false>
 __global__ __launch_bounds__(256, 2) void k(const char* __restrict__ cache, const v2u* __restrict__ srv, v2u* __restrict__ out,
-                                            int pieces, int B) {
+                                            int pieces, int B, int mode = 0, int stride = 0) {
     extern __shared__ float pad[];
     const int t = threadIdx.x;
-    const int team = blockIdx.x, nteams = gridDim.x, chunk = blockIdx.y;
-    const int64_t C = (int64_t)pieces * B;
+    const int team = mode == 2 ? blockIdx.y : blockIdx.x, nteams = mode == 2 ? gridDim.y : gridDim.x;
+    const int chunk = mode == 2 ? blockIdx.x : blockIdx.y;
+    const int64_t C = stride ? stride : (int64_t)pieces * B;
     const char* cch = cache + (int64_t)chunk * pieces * 32768;
     const v2u* s = srv + chunk * C;
     v2u* o = out + chunk * C;
@@ -36,15 +39,22 @@ __global__ __launch_bounds__(256, 2) void k(const char* __restrict__ cache, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) sv[r] = __builtin_amdgcn_raw_buffer_load_b64(rs, t * 8 + 2048 * r, 0, LDS_);
     };
-    issue(team);
+    const int per = (pieces + nteams - 1) / nteams;
+    const int p0 = mode == 1 ? team * per : team, pstep = mode == 1 ? 1 : nteams;
+    const int pend = mode == 1 ? (p0 + per < pieces ? p0 + per : pieces) : pieces;
+    issue(p0 < pend ? p0 : pieces);
+    // mode bit 4: the first loads complete before the loop is entered.  Without it the loop header is reached with loads
+    // pending (from here) or with loads FOLLOWED BY STORES pending (back edge); the compiler's wait must cover both, i.e.
+    // s_waitcnt vmcnt(0) at the top of every iteration -- which also waits for the previous piece's stores
+    if (WAIT_FIRST) __builtin_amdgcn_s_waitcnt(0x0F70);
     unsigned acc = 0;
-    for (int p = team; p < pieces; p += nteams) {
+    for (int p = p0; p < pend; p += pstep) {
         v2u res[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) res[r] = v2u{sv[r].x ^ x[r & 7].x, sv[r].y ^ x[r & 7].w};
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc += x[m].y + x[m].z;
-        issue(p + nteams);
+        issue(p + pstep < pend ? p + pstep : pieces);
         const __amdgpu_buffer_rsrc_t ro = rsrc(o + (int64_t)p * B, (unsigned)B * 8u);
 #pragma unroll
         for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b64(res[r], ro, t * 8 + 2048 * r, 0, ST);
@@ -52,40 +62,46 @@ __global__ __launch_bounds__(256, 2) void k(const char* __restrict__ cache, cons
     if (acc == 0x12345678u) pad[0] = 1.f;
 }
 
-template <int LDC, int LDS_, int ST>
-static void run(void* c, void* s, void* o, int nchunks, int pieces, int B) {
+static void run(void* c, void* s, void* o, int nchunks, int pieces, int B, int teams, int mode, int stride, const char* what, int wait_first = 0) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const double bytes = (double)nchunks * pieces * 32768 + 2.0 * (double)nchunks * pieces * B * 8;
-    hipFuncSetAttribute((const void*)k<LDC, LDS_, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipFuncSetAttribute((const void*)k<0, 0, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    hipFuncSetAttribute((const void*)k<0, 0, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     float best = 1e9;
     for (int rep = 0; rep < 4; ++rep) {
         float ms = 0;
         hipEventRecord(e0);
-        k<LDC, LDS_, ST><<<dim3(9, nchunks), 256, 69 * 1024>>>((const char*)c, (const v2u*)s, (v2u*)o, pieces, B);
+        const dim3 grid = mode == 2 ? dim3(nchunks, teams) : dim3(teams, nchunks);
+        if (wait_first) k<0, 0, 0, true><<<grid, 256, 69 * 1024>>>((const char*)c, (const v2u*)s, (v2u*)o, pieces, B, mode, stride);
+        else k<0, 0, 0, false><<<grid, 256, 69 * 1024>>>((const char*)c, (const v2u*)s, (v2u*)o, pieces, B, mode, stride);
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         if (rep && ms < best) best = ms;
     }
-    printf("aux: cache loads %2d, stream loads %2d, stores %2d : %.3f ms, %.2f TB/s\n", LDC, LDS_, ST, best, bytes / best / 1e9);
+    printf("%-58s B=%d teams=%3d: %.3f ms, %.2f TB/s\n", what, B, teams, best, bytes / best / 1e9);
 }
 
 int main() {
-    const int nchunks = 256, pieces = 314, B = 3831;
-    const size_t cache_b = (size_t)nchunks * pieces * 32768, str_b = (size_t)nchunks * pieces * B * 8;
+    const int nchunks = 256, pieces = 314;
+    const size_t cache_b = (size_t)nchunks * pieces * 32768, str_b = (size_t)nchunks * pieces * 3840 * 8 + 4096;
     void *c, *s, *o;
     hipMalloc(&c, cache_b); hipMalloc(&s, str_b); hipMalloc(&o, str_b);
     hipMemset(c, 1, cache_b); hipMemset(s, 2, str_b);
-    run<0, 0, 0>(c, s, o, nchunks, pieces, B);
-    run<2, 2, 0>(c, s, o, nchunks, pieces, B);
-    run<0, 0, 2>(c, s, o, nchunks, pieces, B);
-    run<2, 2, 2>(c, s, o, nchunks, pieces, B);
-    run<16, 16, 0>(c, s, o, nchunks, pieces, B);
-    run<17, 17, 0>(c, s, o, nchunks, pieces, B);
-    run<18, 18, 18>(c, s, o, nchunks, pieces, B);
-    run<0, 0, 17>(c, s, o, nchunks, pieces, B);
-    run<0, 0, 19>(c, s, o, nchunks, pieces, B);
-    run<2, 0, 0>(c, s, o, nchunks, pieces, B);
-    run<0, 2, 0>(c, s, o, nchunks, pieces, B);
-    run<0, 0, 0>(c, s, o, nchunks, pieces, B);
+    run(c, s, o, nchunks, pieces, 3831, 9, 0, 0, "strided pieces (the kernel)");
+    run(c, s, o, nchunks, pieces, 3840, 9, 0, 0, "line-aligned pieces");
+    run(c, s, o, nchunks, pieces, 3831, 9, 1, 0, "contiguous run of pieces per team");
+    run(c, s, o, nchunks, pieces, 3840, 9, 1, 0, "contiguous run, line-aligned");
+    run(c, s, o, nchunks, pieces, 3831, 9, 2, 0, "chunk index fastest in the grid");
+    run(c, s, o, nchunks, pieces, 3831, 18, 0, 0, "strided");
+    run(c, s, o, nchunks, pieces, 3831, 36, 0, 0, "strided");
+    run(c, s, o, nchunks, pieces, 3831, 314, 0, 0, "one piece per workgroup");
+    run(c, s, o, nchunks, pieces, 3840, 314, 0, 0, "one piece per workgroup, line-aligned");
+    run(c, s, o, nchunks, pieces, 3831, 4, 1, 0, "contiguous run");
+    run(c, s, o, nchunks, pieces, 3831, 2, 1, 0, "contiguous run");
+    run(c, s, o, nchunks, pieces, 3831, 9, 0, 314 * 3831 + 1024, "strided, chunk stride + 8 KB");
+    run(c, s, o, nchunks, pieces, 3831, 9, 0, 0, "strided, first loads waited for before the loop", 1);
+    run(c, s, o, nchunks, pieces, 3840, 9, 0, 0, "  the same, line-aligned", 1);
+    run(c, s, o, nchunks, pieces, 3831, 9, 1, 0, "contiguous run, first loads waited for", 1);
+    run(c, s, o, nchunks, pieces, 3831, 36, 0, 0, "strided, first loads waited for", 1);
     return 0;
 }
