@@ -32,11 +32,33 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_fused_cached_team_kernel(LsF
     float2* __restrict__ out = a.out + (int64_t)b * a.out_stride;
     const double2* __restrict__ taps = a.taps_t + (int64_t)b * a.T;
     const int n = (int)a.n;
-    const int T = a.T, B = a.piece, ext = T - 1, peek = a.peek;
+    const int T = a.T, B = a.piece, peek = a.peek;
+    const int ext = FT_P - B;                                 // slot origin of a piece: >= T - 1 (ltc_piece)
     const int nblocks = (n + B - 1) / B;
     const float2* __restrict__ cache = a.cache + (int64_t)b * nblocks * FT_P;
     const unsigned vo8 = (unsigned)t * 8u;
     const unsigned vslot = vo8 - (unsigned)ext * 8u;
+
+    float2 xn[16];
+    auto issue_x = [&](int p) {
+        const bool live = p < nblocks;
+#ifdef LTC_EXP_NOLOAD       // timing ablation only (wrong results): no global loads
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xn[r] = make_float2((float)(t + p), (float)r);
+        return;
+#endif
+        const __amdgpu_buffer_rsrc_t rc = prc_rsrc(cache + (int64_t)(live ? p : 0) * FT_P, live ? FT_P * 8u : 0u);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) prc_buf_load_2c64(rc, (unsigned)t * 16u, 4096u * m, xn[2 * m], xn[2 * m + 1]);
+    };
+    // a contiguous run of pieces per team (stream4.hip: +3 % over pieces team, team + nteams, ...)
+#ifdef LTC_STRIDED
+    const int p0 = team, pstep = nteams, pend = nblocks;
+#else
+    const int per = (nblocks + nteams - 1) / nteams;
+    const int p0 = team * per, pstep = 1, pend = p0 + per < nblocks ? p0 + per : nblocks;
+#endif
+    issue_x(p0 < pend ? p0 : nblocks);                        // flies under the transform of the taps
 
     // H~ = FFT(taps) / 4096 of this block (frequency layout); element (r, t) is private to thread t and parked in LDS
     float2* Hs = lds + FT_LDS_ELEMS + t;
@@ -58,20 +80,8 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_fused_cached_team_kernel(LsF
 #pragma unroll
     for (int m = 0; m < 16; ++m) wrs[m] = make_float2(0.f, 0.f);
 
-    float2 xn[16];
-    auto issue_x = [&](int p) {
-        const bool live = p < nblocks;
-#ifdef LTC_EXP_NOLOAD       // timing ablation only (wrong results): no global loads
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xn[r] = make_float2((float)(t + p), (float)r);
-        return;
-#endif
-        const __amdgpu_buffer_rsrc_t rc = prc_rsrc(cache + (int64_t)(live ? p : 0) * FT_P, live ? FT_P * 8u : 0u);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) prc_buf_load_2c64(rc, (unsigned)t * 16u, 4096u * m, xn[2 * m], xn[2 * m + 1]);
-    };
-    issue_x(team);
-    for (int p = team; p < nblocks; p += nteams) {
+    ltc_loads_landed();
+    for (int p = p0; p < pend; p += pstep) {
         const int n0 = p * B;
         const int cnt = (n - n0) < B ? (n - n0) : B;
         float2 xc[16], y[16], sv[16];
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_fused_cached_team_kernel(LsF
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[r] = cmul(xc[r], Hs[FT_THREADS * r]);
         __builtin_amdgcn_sched_barrier(0);
-        issue_x(p + nteams);
+        issue_x(p + pstep < pend ? p + pstep : nblocks);
         {
 #ifdef LTC_EXP_NOLOAD
 #pragma unroll
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_fused_cached_team_kernel(LsF
 }
 
 int64_t ls_team_cache_elems_per_block(int64_t n, int T) {
-    const int64_t B = FT_P - (T - 1);
+    const int64_t B = ltc_piece(T);
     return ((n + B - 1) / B) * FT_P;
 }
 
@@ -174,7 +184,7 @@ int ls_team_chain_teams_per_block(int64_t n, int T, int max_blocks) {
     // keeps four pieces
     int per = 32;
     if (const char* e = getenv("PRC_LS_TEAM_PIECES")) { const int v = atoi(e); if (v > 0) per = v; }
-    const int64_t B = FT_P - (T - 1);
+    const int64_t B = ltc_piece(T);
     const int64_t pieces = (n + B - 1) / B;
     int64_t teams = pieces / per;
     int64_t fill = (2048 + max_blocks - 1) / max_blocks;

@@ -15,7 +15,8 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_corr_cached_team_kernel(LsFf
     const float2* __restrict__ ref = a.ref + (int64_t)b * a.ref_stride;
     const float2* __restrict__ srv = a.srv + (int64_t)b * a.srv_stride;
     const int n = (int)a.n;
-    const int T = a.T, B = a.piece, ext = T - 1, peek = a.peek;
+    const int T = a.T, B = a.piece, peek = a.peek;
+    const int ext = FT_P - B;                                 // slot origin of a piece: >= T - 1 (ltc_piece)
     const int npieces = (n + B - 1) / B;
     float2* __restrict__ cache = a.cache + (int64_t)b * npieces * FT_P;
     const unsigned vo8 = (unsigned)t * 8u;
@@ -36,8 +37,15 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_corr_cached_team_kernel(LsFf
 #pragma unroll
         for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rx, voff + 2048u * r, 0u);
     };
-    issue_x(team);
-    for (int p = team; p < npieces; p += nteams) {
+#ifdef LTC_STRIDED
+    const int p0 = team, pstep = nteams, pend = npieces;
+#else
+    const int per = (npieces + nteams - 1) / nteams;          // a contiguous run of pieces per team
+    const int p0 = team * per, pstep = 1, pend = p0 + per < npieces ? p0 + per : npieces;
+#endif
+    issue_x(p0 < pend ? p0 : npieces);
+    ltc_loads_landed();
+    for (int p = p0; p < pend; p += pstep) {
         const int n0 = p * B;
         const int cnt = (n - n0) < B ? (n - n0) : B;
         const int mstart = n0 - ext;
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_corr_cached_team_kernel(LsFf
                 u[r] = cmul(u[r], cmul(sbase, st));
             }
         }
-        issue_x(p + nteams);
+        issue_x(p + pstep < pend ? p + pstep : npieces);
         __builtin_amdgcn_sched_barrier(0);
         ft4096_fwd<0>(u, f);
         if (FT_NBUF == 2) ft_team_sync();                     // three transforms per piece: the next piece starts at buffer 0 again

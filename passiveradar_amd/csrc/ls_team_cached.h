@@ -4,6 +4,7 @@
 #include "ls_internal.h"
 #include "fft_team.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define LTC_SPEC FT_P                        // float2 of per-thread spectrum kept in LDS behind the transform's area
 static constexpr size_t LTC_LDS = sizeof(float2) * (FT_LDS_ELEMS + LTC_SPEC);
@@ -17,8 +18,27 @@ __device__ __forceinline__ void ltc_cmac_bconj(float2& w, float2 u, float2 x) { 
     w.y = fmaf(-u.x, x.y, w.y);
 }
 
+// Samples per piece.  The slot origin E (history in slots [0, E), the piece in [E, E + B)) is T - 1 rounded up to 16
+// samples, so that every piece starts on a 128-byte line of the streams (tools/ubench/stream4.hip: +4 .. 8 % of HBM rate
+// for the same bytes); PRC_LS_TEAM_ALIGN=0 keeps E = T - 1 (A/B runs).
+static inline int ltc_piece(int T) {
+    static const int align = [] { const char* e = getenv("PRC_LS_TEAM_ALIGN"); return e ? atoi(e) : 1; }();
+    const int E = align ? ((T - 1 + 15) & ~15) : T - 1;
+    return FT_P - E;
+}
+
+// All loads issued so far have landed.  Placed between the first prefetch and a loop that prefetches AND stores: without
+// it the loop head is reached with loads pending (first entry) or with loads followed by stores pending (back edge), the
+// compiler's wait has to cover both, and it becomes an s_waitcnt vmcnt(0) on every iteration -- which also waits for the
+// stores of the previous piece (vmcnt counts loads and stores in order on gfx9).  tools/ubench/stream4.hip: +5 % of HBM rate.
+__device__ __forceinline__ void ltc_loads_landed() {
+#ifndef LTC_NO_WAIT_FIRST
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt and lgkmcnt untouched
+#endif
+}
+
 static inline void ltc_fill(LsFftArgs& a, double theta) {
-    a.piece = FT_P - (a.T - 1);
+    a.piece = ltc_piece(a.T);
     a.theta32 = (float)theta;
     for (int r = 0; r < 16; ++r) {
         const double ang = theta * (double)FT_THREADS * r;

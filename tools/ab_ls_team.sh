@@ -1,15 +1,17 @@
-mkdir -p gpurun_out/lstc2
+# A/B runs of the 4096-point LS chain on one box: bash tools/ab_ls_team.sh  (prints one line per variant)
+mkdir -p gpurun_out/lstc4
 run() { # name, env...
   name=$1; shift
-  env "$@" timeout 120 python bench.py --no-cpu --steps 3 --warmup 1 $ARGS > gpurun_out/lstc2/$name.json 2>gpurun_out/lstc2/$name.err
+  env "$@" timeout 120 python bench.py --no-cpu $ARGS > gpurun_out/lstc4/$name.json 2>gpurun_out/lstc4/$name.err
   python - <<PY
 import json
-j=json.loads(open("gpurun_out/lstc2/$name.json").read().strip().splitlines()[-1])
+j=json.loads(open("gpurun_out/lstc4/$name.json").read().strip().splitlines()[-1])
 k=j["kernels"]
-print("$name", round(j["value"]), "corr", round(k["ls_correlate"]["avg_ms_per_launch"],3), "solve", round(k["ls_solve"]["avg_ms_per_launch"],4), "fused", round(k["ls_fir_subtract"]["avg_ms_per_launch"],3))
+print("$name", round(j["value"]), "corr", round(k["ls_correlate"]["avg_ms_per_launch"],3), "solve", round(k["ls_solve"]["avg_ms_per_launch"],4), "fused", round(k["ls_fir_subtract"]["avg_ms_per_launch"],3), "frac", round(j["roofline"]["frac"],3))
 PY
 }
-ARGS="--ls-method 0" run m0 A=1
-for p in 8 16 32 64; do ARGS="--ls-method 4" run m4_p$p PRC_LS_TEAM_PIECES=$p; done
-ARGS="--ls-method 4" run m4_tw2reg_p16 PRC_LS_TEAM_PIECES=16 PRCORE_LIB=$PWD/passiveradar_amd/libprcore_tw2reg.so
-ARGS="--ls-method 0" run m0b A=1
+ARGS="" run auto A=1
+ARGS="" run auto_unaligned PRC_LS_TEAM_ALIGN=0
+ARGS="--ls-method 3" run m3 A=1
+ARGS="" run auto_b A=1
+ARGS="" run auto_unaligned_b PRC_LS_TEAM_ALIGN=0
