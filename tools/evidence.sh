@@ -32,6 +32,17 @@ pmc() {   # pmc <name> <bench args...>: one pass per counter group
   done
   grep '^{' $E/$name.g1.log | tail -1 > $E/$name.json
 }
+# EV_ONLY=cfg2 tools/evidence.sh r03 : only the runs of the headline configuration (the raw files of the other runs stay as
+# they are under gpurun_out/ev_<tag>/; run tools/evidence_summarize.py afterwards where all of them are)
+if [ "$EV_ONLY" = "cfg2" ]; then
+  run bench_default $B --cpu-asis
+  run bench_cfg4 $B --workload cfg4 --no-cpu
+  trace trace_cfg2 --no-cpu --frames 1024 --steps 5 --warmup 1
+  trace trace_cfg2_serial --no-cpu --frames 1024 --steps 5 --warmup 1 --no-overlap
+  pmc pmc_cfg2 --no-cpu --frames 256 --steps 2 --warmup 1 --no-overlap
+  python3 $R/tools/evidence_summarize.py $tag
+  exit 0
+fi
 # 1. the bench lines of record (default with the CPU leg and the as-is figure; the other configs with their CPU legs)
 run bench_default $B --cpu-asis
 run bench_default_allcores $B --steps 5 --cpu-workers all

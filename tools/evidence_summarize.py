@@ -65,7 +65,8 @@ for name in ("trace_cfg2", "trace_cfg2_serial", "trace_cfg3", "trace_cfg5"):
 # ---- counters --------------------------------------------------------------------------------------------------------
 FAMILY = {"caf_segments": ("caf_fft_kernel", "caf_fft_team_kernel", "caf_fft_team_multi_kernel", "caf_direct_kernel"),
           "caf_doppler": ("doppler_col_kernel", "shift_transpose_kernel", "transpose_jk_kj_kernel"),
-          "ls_correlate": ("ls_corr_cached_kernel",), "ls_fir_subtract": ("ls_fused_cached_kernel",),
+          "ls_correlate": ("ls_corr_cached_kernel", "ls_corr_cached_team_kernel"),
+          "ls_fir_subtract": ("ls_fused_cached_kernel", "ls_fused_cached_team_kernel"),
           "ls_solve": ("ls_solve_gs_kernel", "ls_prepare_kernel")}
 traffic = {"_note": "HBM traffic in bytes per processed unit (one hop chunk for ls_*, one frame/surface for caf_*): rocprofv3 --pmc FETCH_SIZE and "
                     "--pmc WRITE_SIZE in separate passes (tools/evidence.sh), 2 x FETCH_SIZE + WRITE_SIZE (gfx950 reports half the bytes of wide "

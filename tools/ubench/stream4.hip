@@ -87,21 +87,14 @@ int main() {
     void *c, *s, *o;
     hipMalloc(&c, cache_b); hipMalloc(&s, str_b); hipMalloc(&o, str_b);
     hipMemset(c, 1, cache_b); hipMemset(s, 2, str_b);
-    run(c, s, o, nchunks, pieces, 3831, 9, 0, 0, "strided pieces (the kernel)");
-    run(c, s, o, nchunks, pieces, 3840, 9, 0, 0, "line-aligned pieces");
-    run(c, s, o, nchunks, pieces, 3831, 9, 1, 0, "contiguous run of pieces per team");
-    run(c, s, o, nchunks, pieces, 3840, 9, 1, 0, "contiguous run, line-aligned");
-    run(c, s, o, nchunks, pieces, 3831, 9, 2, 0, "chunk index fastest in the grid");
-    run(c, s, o, nchunks, pieces, 3831, 18, 0, 0, "strided");
-    run(c, s, o, nchunks, pieces, 3831, 36, 0, 0, "strided");
+    run(c, s, o, nchunks, pieces, 3831, 9, 0, 0, "strided pieces (round 3's order)");
+    run(c, s, o, nchunks, pieces, 3840, 9, 0, 0, "  line-aligned pieces");
+    run(c, s, o, nchunks, pieces, 3831, 9, 0, 0, "  first loads landed before the loop", 1);
+    run(c, s, o, nchunks, pieces, 3831, 9, 1, 0, "  + a contiguous run of pieces per team", 1);
+    run(c, s, o, nchunks, pieces, 3840, 9, 1, 0, "  + line-aligned (the kernel)", 1);
+    for (int teams : {18, 36, 78, 157, 314}) run(c, s, o, nchunks, pieces, 3840, teams, 1, 0, "  the kernel's order with more teams per chunk", 1);
+    for (int teams : {36, 78, 157}) run(c, s, o, nchunks, pieces, 3840, teams, 0, 0, "  strided, more teams per chunk", 1);
     run(c, s, o, nchunks, pieces, 3831, 314, 0, 0, "one piece per workgroup");
     run(c, s, o, nchunks, pieces, 3840, 314, 0, 0, "one piece per workgroup, line-aligned");
-    run(c, s, o, nchunks, pieces, 3831, 4, 1, 0, "contiguous run");
-    run(c, s, o, nchunks, pieces, 3831, 2, 1, 0, "contiguous run");
-    run(c, s, o, nchunks, pieces, 3831, 9, 0, 314 * 3831 + 1024, "strided, chunk stride + 8 KB");
-    run(c, s, o, nchunks, pieces, 3831, 9, 0, 0, "strided, first loads waited for before the loop", 1);
-    run(c, s, o, nchunks, pieces, 3840, 9, 0, 0, "  the same, line-aligned", 1);
-    run(c, s, o, nchunks, pieces, 3831, 9, 1, 0, "contiguous run, first loads waited for", 1);
-    run(c, s, o, nchunks, pieces, 3831, 36, 0, 0, "strided, first loads waited for", 1);
     return 0;
 }
