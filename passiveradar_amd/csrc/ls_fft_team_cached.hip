@@ -3,12 +3,13 @@
 // Same algebra and the same edge handling as ls_corr_cached_kernel / ls_fused_cached_kernel of ls_fft.hip (read the
 // comment block there first); the only change is the transform length.  Why it pays: both kernels are bound by HBM
 // traffic, and the spectrum cache costs P complex64 per piece of P - (T-1) new samples.  For the T = 266 taps of the
-// headline configuration that is 8192 B / 759 samples = 10.8 B per sample with P = 1024 and 32768 B / 3831 samples
+// headline configuration that is 8192 B / 759 samples = 10.8 B per sample with P = 1024 and 32768 B / 3824 samples
 // = 8.6 B per sample with P = 4096, next to the 16 B per sample of reading the stream and writing it back.
 //
 // One workgroup (four wavefronts, fft_team.h) per piece.  Slot idx = 256 r + t of a piece at n0 holds rho[n0 - ext + idx]
 // for the block spectrum X_p and the (surveillance / cleaned) sample n0 + idx - ext in slots [ext, ext + cnt) for the
-// correlation inputs.  Compiled with one exchange buffer (FT_NBUF = 1, Makefile): 36 KB of exchange + 32 KB of
+// correlation inputs, where the slot origin ext = T - 1 rounded up to 16 samples (ltc_piece: pieces then start on
+// 128-byte lines; the extra history slots are harmless to the overlap-save FIR and to the lags 0 .. T-1).  Compiled with one exchange buffer (FT_NBUF = 1, Makefile): 36 KB of exchange + 32 KB of
 // per-thread spectrum (autocorrelation accumulator / tap spectrum) = 68 KB per workgroup, two workgroups per CU.
 // This file: the fused FIR + correlation kernel, with the T2 twiddles factored (FT_TW2_FACTORED: 2 VGPRs instead of 32 --
 // with 32 it spills and runs 28 % slower); the first-bin kernel sits in ls_fft_team_corr_cached.hip, which keeps them in
