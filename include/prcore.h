@@ -166,9 +166,10 @@ int prc_ls_set_profiling(prc_ls_plan* plan, int32_t enable);
 int prc_ls_get_profile(prc_ls_plan* plan, double* ms, int32_t* launches_per_kind);
 
 /* ---- NLMS_filter (clutter_removal.py:189-249) ---------------------------------------- */
-/* LIMIT: filter_len + peek <= 2048 taps (a stream's taps live in the registers of one wavefront, 32 per lane);
- * beyond that PRC_EUNSUPPORTED -- the reference (clutter_removal.py:189-249) accepts any length.
- * nstreams independent sample-recursive filters, one wavefront each.  taps_in: optional
+/* LIMIT: filter_len + peek <= 8192 taps (a stream's taps live in registers, 32 per lane: one wavefront up to 2048 taps,
+ * a workgroup of two up to 4096, of four up to 8192); beyond that PRC_EUNSUPPORTED -- the reference
+ * (clutter_removal.py:189-249) accepts any length.
+ * nstreams independent sample-recursive filters, one wavefront (or one such workgroup) each.  taps_in: optional
  * complex64 [nstreams][T] initial taps (initialTaps), NULL = zeros.  taps_out: optional
  * complex64 [nstreams][T].  out: complex64, zero outside [filter_len, n-peek). */
 int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int64_t stride,

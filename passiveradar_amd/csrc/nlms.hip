@@ -15,6 +15,12 @@
 // (= 1, 2 or 3 per SIMD) and asks for more than half of the CU's LDS: exactly one workgroup per CU, its
 // wavefronts dealt round-robin to the four SIMDs.  Wavefronts never share LDS data, so there is no
 // workgroup barrier anywhere.
+//
+// Beyond the 2048 taps one wavefront's registers hold (NW = 2: up to 4096 taps, NW = 4: up to 8192; the reference
+// takes any length, :189-249) a stream is ONE workgroup of NW wavefronts: consecutive tap ranges of T/NW taps each, one
+// shared LDS window, and per step one exchange of the NW partial sums of w^H u through LDS (double-buffered slots, one
+// workgroup barrier per step; every wavefront adds the partials in the same order, so all of them see the same error
+// sample).  Each wavefront slides the energy of the WHOLE tap window itself (two more broadcast LDS reads per step).
 #include "common.h"
 
 struct NlmsArgs {
@@ -99,49 +105,61 @@ __device__ __forceinline__ float wave_shr1(float lane0, float src) {
 // sample, and the new sample enters lane 0 from a broadcast LDS read.  A short lane's spare register is re-zeroed every step
 // (its index is a compile-time constant).  Round 2 spread taps lane-minor (tap = lane + 64 t) and re-read the whole window
 // from LDS every step: 17 ds_read_b64 per step at T = 1034 against 1 now, and its two all-lane sums are one (wave_allsum2).
-template <int TPL, int MAXW>
-__global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
+// NW = 1: MAXW independent streams per workgroup, one wavefront each.  NW > 1: one stream per workgroup of NW wavefronts.
+template <int TPL, int MAXW, int NW = 1>
+__global__ __launch_bounds__(64 * (NW > 1 ? NW : MAXW)) void nlms_kernel(NlmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int KT = a.kt;
     const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float2* Rw = reinterpret_cast<float2*>(smem_raw) + (size_t)wave_id * (2 * KT + 64 * TPL);   // KT + 64*TPL : ref window
-    float2* D = Rw + KT + 64 * TPL;                     // KT : srv in, error out
+    constexpr int WIN = 64 * TPL * NW;                  // >= T: the window of all the stream's taps
+    float2* Rw = reinterpret_cast<float2*>(smem_raw) + (NW > 1 ? (size_t)0 : (size_t)wave_id * (2 * KT + WIN));   // KT + WIN : ref window
+    float2* D = Rw + KT + WIN;                          // KT : srv in, error out
+    float2* S = D + KT;                                 // NW > 1: partial sums of w^H u, [step parity][wavefront]
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * (int)(blockDim.x >> 6) + wave_id;
-    if (b >= a.nstreams) return;                        // no barriers below: idle wavefronts just leave
+    const int tid = NW > 1 ? (int)threadIdx.x : lane;   // index and stride of the loops that stage / drain the LDS windows
+    constexpr int NT = 64 * NW;
+    const int b = NW > 1 ? (int)blockIdx.x : blockIdx.x * (int)(blockDim.x >> 6) + wave_id;
+    if (b >= a.nstreams) return;                        // NW = 1: no barriers below, idle wavefronts just leave
     const float2* __restrict__ ref = a.ref + (int64_t)b * a.stride;
     const float2* __restrict__ srv = a.srv + (int64_t)b * a.stride;
     float2* __restrict__ out = a.out + (int64_t)b * a.out_stride;
     const int T = a.T;
     const int64_t nsteps = a.n - T;   // k = 0..nsteps-1 (may be <= 0)
-    const int A = T - 64 * (TPL - 1);                   // 1 <= A <= 64 lanes with TPL taps
+    // this wavefront's taps: oq .. oq + Tq - 1 (an even split: 64 (TPL - 1) <= Tq <= 64 TPL for every wavefront)
+    int Tq = T, oq = 0;
+    if (NW > 1) {
+        const int lo = T / NW, extra = T % NW;
+        Tq = lo + (wave_id < extra ? 1 : 0);
+        oq = wave_id * lo + (wave_id < extra ? wave_id : extra);
+    }
+    const int A = Tq - 64 * (TPL - 1);                  // 0 <= A <= 64 lanes with TPL taps
     const bool full = lane < A;
     const int i0 = full ? lane * TPL : A * TPL + (lane - A) * (TPL - 1);
     const int ntap = full ? TPL : TPL - 1;
+    auto team_fence = [&]() { if (NW > 1) __syncthreads(); else wave_lds_fence(); };
 
     v2f w[TPL];
 #pragma unroll
     for (int t = 0; t < TPL; ++t) {
-        const float2 w0 = (a.taps_in && t < ntap) ? a.taps_in[(int64_t)b * T + i0 + t] : make_float2(0.f, 0.f);
+        const float2 w0 = (a.taps_in && t < ntap) ? a.taps_in[(int64_t)b * T + oq + i0 + t] : make_float2(0.f, 0.f);
         w[t] = v2f{w0.x, w0.y};
     }
     // out[0:L] = 0 and out[n-peek:] = 0 (:231)
-    for (int64_t i = lane; i < a.n; i += 64)
+    for (int64_t i = tid; i < a.n; i += NT)
         if (i < a.L || i >= a.L + (nsteps > 0 ? nsteps : 0)) out[i] = make_float2(0.f, 0.f);
 
-    const int WIN = 64 * TPL;   // >= T
     for (int64_t k0 = 0; k0 < nsteps; k0 += KT) {
         const int64_t rem = nsteps - k0;
         const int cnt = rem < KT ? (int)rem : KT;
-        wave_lds_fence();
+        team_fence();
         // window element x <-> ref[k0 + 1 - (WIN - T) + x];  u_kk[i] = Rw[kk + WIN - 1 - i]
         const int64_t base = k0 + 1 - (WIN - T);
-        for (int x = lane; x < KT + WIN; x += 64) {
+        for (int x = tid; x < KT + WIN; x += NT) {
             const int64_t idx = base + x;
             Rw[x] = (idx >= 0 && idx < a.n) ? ref[idx] : make_float2(0.f, 0.f);
         }
-        for (int x = lane; x < cnt; x += 64) D[x] = srv[k0 + x + a.L];
-        wave_lds_fence();
+        for (int x = tid; x < cnt; x += NT) D[x] = srv[k0 + x + a.L];
+        team_fence();
         // u^H u is summed at the start of every staged window and then slid IN DOUBLE PRECISION:
         //   E(k+1) = E(k) + |ref[T+k+1]|^2 - |ref[k+1]|^2      (window element kk+WIN enters, kk+WIN-T leaves)
         // The reference re-sums at every step (:213), so its value never carries cancellation error.  A float32
@@ -155,10 +173,16 @@ __global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
             double e0 = 0.0;
 #pragma unroll
             for (int t = 0; t < TPL; ++t) {
-                float2 v = Rw[WIN - 1 - (i0 + t)];
+                float2 v = Rw[WIN - 1 - (oq + i0 + t)];
                 if (t >= ntap) v = make_float2(0.f, 0.f);
-                e0 = fma((double)v.x, (double)v.x, fma((double)v.y, (double)v.y, e0));
+                if (NW == 1) e0 = fma((double)v.x, (double)v.x, fma((double)v.y, (double)v.y, e0));
                 P[t] = v2f{v.x, v.y};
+            }
+            if (NW > 1) {                              // the energy of ALL T taps, summed by every wavefront in the same order
+                for (int i = lane; i < T; i += 64) {
+                    const float2 v = Rw[WIN - 1 - i];
+                    e0 = fma((double)v.x, (double)v.x, fma((double)v.y, (double)v.y, e0));
+                }
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) e0 += __shfl_xor(e0, m, 64);
@@ -170,7 +194,9 @@ __global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
                 const int kk = kk0 + j;
                 if (kk < cnt) {                        // uniform (no break: the unrolled body keeps its constant register indices)
                     // the sample that enters tap 0 at the next step (also the one entering the energy window), the one leaving it
-                    const float2 vin = Rw[kk + WIN], vout = Rw[kk + WIN - T];
+                    // (NW > 1: vin enters THIS wavefront's first tap, vtot the stream's)
+                    const float2 vin = Rw[kk + WIN - oq], vout = Rw[kk + WIN - T];
+                    const float2 vtot = NW > 1 ? Rw[kk + WIN] : vin;
                     const float2 d = D[kk];
                     // conj(w) . u on packed FMAs, two chains opened by a product (no zeroed accumulators to set up)
                     v2f acc0 = pk_cmul_conj(w[0], P[(0 - j + TPL) % TPL]);
@@ -180,9 +206,21 @@ __global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
                     const v2f ysum = acc0 + acc1;
                     float yr = ysum.x, yi = ysum.y;
                     wave_allsum2(yr, yi);
+                    if (NW > 1) {
+                        // partial sums of the NW tap ranges: slots of this step's parity (the other parity is still being read
+                        // by a wavefront that has not left the previous step), one barrier, the same order of addition everywhere
+                        float2* Sk = S + (kk & 1) * NW;
+                        if (lane == 0) Sk[wave_id] = make_float2(yr, yi);
+                        __syncthreads();
+                        float sr = 0.f, si = 0.f;
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) { const float2 pq = Sk[q]; sr += pq.x; si += pq.y; }
+                        yr = sr;
+                        yi = si;
+                    }
                     const float en = (float)energy;
                     {
-                        const double ix = (double)vin.x, iy = (double)vin.y, ox = (double)vout.x, oy = (double)vout.y;
+                        const double ix = (double)vtot.x, iy = (double)vtot.y, ox = (double)vout.x, oy = (double)vout.y;
                         energy = fma(ix, ix, energy);
                         energy = fma(iy, iy, energy);
                         energy = fma(-ox, ox, energy);
@@ -195,7 +233,7 @@ __global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
                     const v2f c = {er * s, ei * s};
 #pragma unroll
                     for (int t = 0; t < TPL; ++t) pk_cmac_bconj(w[t], P[(t - j + TPL) % TPL], c);
-                    if (lane == 0) D[kk] = make_float2(er, ei);
+                    if (lane == 0 && (NW == 1 || wave_id == 0)) D[kk] = make_float2(er, ei);   // every wavefront read d before the barrier
                     // shift: a lane's last VALID sample (tap TPL-1, or TPL-2 in a short lane) goes to the next lane's
                     // tap 0, the new sample to lane 0's; the slot of the old last tap, P[TPL-1-j], is tap 0 of step j+1
                     v2f carry = P[TPL - 1 - j];
@@ -213,13 +251,13 @@ __global__ __launch_bounds__(64 * MAXW) void nlms_kernel(NlmsArgs a) {
                 }
             }
         }
-        wave_lds_fence();
-        for (int x = lane; x < cnt; x += 64) out[a.L + k0 + x] = D[x];
+        team_fence();
+        for (int x = tid; x < cnt; x += NT) out[a.L + k0 + x] = D[x];
     }
     if (a.taps_out) {
 #pragma unroll
         for (int t = 0; t < TPL; ++t)
-            if (t < ntap) a.taps_out[(int64_t)b * T + i0 + t] = make_float2(w[t].x, w[t].y);
+            if (t < ntap) a.taps_out[(int64_t)b * T + oq + i0 + t] = make_float2(w[t].x, w[t].y);
     }
 }
 
@@ -232,9 +270,10 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
                 "prc_nlms_execute: non-positive size");
     PRC_REQUIRE(stride >= n && out_stride >= n, PRC_ESHAPE, "prc_nlms_execute: stride shorter than n");
     const int T = filter_len + peek;
-    const int tpl = (T + 63) / 64;
-    PRC_REQUIRE(tpl <= 32, PRC_EUNSUPPORTED,
-                "prc_nlms_execute: %d taps exceed the single-wavefront kernel (max 2048)", T);
+    PRC_REQUIRE(T <= 8192, PRC_EUNSUPPORTED,
+                "prc_nlms_execute: %d taps exceed the four-wavefront kernel (max 8192)", T);
+    const int nwave = T <= 2048 ? 1 : (T <= 4096 ? 2 : 4);       // wavefronts per stream
+    const int tpl = ((T + nwave - 1) / nwave + 63) / 64;          // taps per lane: <= 32
     NlmsArgs a;
     a.ref = (const float2*)ref;
     a.srv = (const float2*)srv;
@@ -261,6 +300,35 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
         if (cost < best) { best = cost; nw = w; }
     }
     const size_t lds_cu = 160 * 1024;
+    int dev = 0;
+    PRC_HIP(hipGetDevice(&dev));
+    if (nwave > 1) {
+        // one stream per workgroup of nwave wavefronts; two workgroups per CU where the window allows it
+        int kt = 1024;
+        const size_t win = (size_t)64 * tpl * nwave;
+        while (kt > 128 && (2 * (size_t)kt + win + 2 * nwave) * sizeof(float2) > 80 * 1024) kt >>= 1;
+        a.kt = kt;
+        const size_t lds = (2 * (size_t)kt + win + 2 * nwave) * sizeof(float2);
+#define PRC_NLMS_TEAM_CASE(G)                                                                   \
+    case G: {                                                                                   \
+        const void* fn = nwave == 2 ? reinterpret_cast<const void*>(&nlms_kernel<G, 1, 2>)      \
+                                    : reinterpret_cast<const void*>(&nlms_kernel<G, 1, 4>);     \
+        { int rc_ = prc_lds_optin(fn, (int)lds_cu); if (rc_) return rc_; }                      \
+        if (nwave == 2) hipLaunchKernelGGL((nlms_kernel<G, 1, 2>), dim3(nstreams), dim3(128), lds, (hipStream_t)stream, a); \
+        else hipLaunchKernelGGL((nlms_kernel<G, 1, 4>), dim3(nstreams), dim3(256), lds, (hipStream_t)stream, a); \
+        PRC_LAUNCH_CHECK();                                                                     \
+        return PRC_OK;                                                                          \
+    }
+        switch (tpl) {
+            PRC_NLMS_TEAM_CASE(17) PRC_NLMS_TEAM_CASE(18) PRC_NLMS_TEAM_CASE(19) PRC_NLMS_TEAM_CASE(20)
+            PRC_NLMS_TEAM_CASE(21) PRC_NLMS_TEAM_CASE(22) PRC_NLMS_TEAM_CASE(23) PRC_NLMS_TEAM_CASE(24)
+            PRC_NLMS_TEAM_CASE(25) PRC_NLMS_TEAM_CASE(26) PRC_NLMS_TEAM_CASE(27) PRC_NLMS_TEAM_CASE(28)
+            PRC_NLMS_TEAM_CASE(29) PRC_NLMS_TEAM_CASE(30) PRC_NLMS_TEAM_CASE(31) PRC_NLMS_TEAM_CASE(32)
+            default: break;
+        }
+#undef PRC_NLMS_TEAM_CASE
+        return PRC_EUNSUPPORTED;
+    }
     int kt = 1024;
     while (kt > 64 && (size_t)nw * (2 * kt + 64 * tpl) * sizeof(float2) > lds_cu) kt >>= 1;
     a.kt = kt;
@@ -268,8 +336,6 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
     PRC_REQUIRE(lds <= lds_cu, PRC_EUNSUPPORTED, "prc_nlms_execute: %d taps do not fit the LDS window", T);
     if (lds < 84 * 1024) lds = 84 * 1024;              // more than half a CU's LDS: one workgroup per CU
     const int grid = (int)ceil_div64(nstreams, nw);
-    int dev = 0;
-    PRC_HIP(hipGetDevice(&dev));
     // one instantiation per taps-per-lane count: the kernel masks only the LAST 64-tap group against T, so the
     // group count must be exact (a coarser bucket list once left whole groups beyond T unmasked)
 #define PRC_NLMS_CASE(G, W)                                                                     \

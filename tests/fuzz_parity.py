@@ -109,6 +109,8 @@ def worker(wseed):
           note("ls_multiple", rel(LS_Filter_Multiple(ref, srv, L, fs, bins), O.LS_Filter_Multiple(ref, srv, L, fs, bins)), 1e-4, ("multi", N, L, fs, bins))
       elif k == 3:    # NLMS
           N = int(rng.integers(200, 6000)); L = int(rng.integers(1, 2030)); mu = float(rng.choice([0.01, 0.05, 0.2]))
+          if rng.random() < 0.2:          # two / four wavefronts per stream (2049 .. 8192 taps)
+              L = int(rng.integers(2030, 8180)); N = L + 10 + int(rng.integers(50, 1200))
           ref, srv = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
           note("nlms", rel(NLMS_filter(ref, srv, L, mu), c_oracle.nlms(ref, srv, L, mu)[0]) if N > L + 10 else 0.0, 1e-4, ("nlms", N, L, mu))
       elif k == 4:    # xcorr

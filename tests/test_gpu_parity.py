@@ -335,7 +335,7 @@ def test_ls_chain_first_bin_rotated():
         assert rel_err(got, exp) < TOL, bins
 
 
-@pytest.mark.parametrize("L", [54, 55, 118, 375, 390, 438, 439, 600, 1014, 1015, 1200, 1700, 2038])
+@pytest.mark.parametrize("L", [54, 55, 118, 375, 390, 438, 439, 600, 1014, 1015, 1200, 1700, 1800, 1960, 2038])
 def test_nlms_every_tap_group_count(L):
     """one kernel instantiation per 64-tap group count: T = L + 10 on both sides of group boundaries and in the
     middle of what used to be coarse buckets (7, 10, 19, 27 groups), where whole groups beyond T must stay zero"""
@@ -346,6 +346,30 @@ def test_nlms_every_tap_group_count(L):
     out, taps = NLMS_filter(ref, srv, L, 0.05, 10, None, True)
     exp, etaps = c_oracle.nlms(ref, srv, L, 0.05, 10)
     assert rel_err(out, exp) < TOL and rel_err(taps, etaps) < TOL
+
+
+@pytest.mark.parametrize("L", [2039, 2040, 3001, 4086, 4087, 6000, 8182])
+def test_nlms_beyond_one_wavefront(L):
+    """filters longer than the 2048 taps one wavefront holds (the reference takes any length, clutter_removal.py:189-249):
+    a stream becomes a workgroup of two (T <= 4096) or four (T <= 8192) wavefronts with consecutive tap ranges -- T = 2049
+    (uneven split 1025 + 1024), 2050, 3011, 4096, 4097 (four wavefronts, 1025 + 3 x 1024), 6010, 8192; cold and warm start"""
+    from oracle import c_oracle
+    from passiveradar_amd.clutter_removal import NLMS_filter
+    n = L + 10 + 1300
+    ref, srv = scene.make_scene(n, 1e4, 50, 7000 + L)
+    out, taps = NLMS_filter(ref, srv, L, 0.05, 10, None, True)
+    exp, etaps = c_oracle.nlms(ref, srv, L, 0.05, 10)
+    assert rel_err(out, exp) < TOL and rel_err(taps, etaps) < TOL
+    out2, taps2 = NLMS_filter(ref, srv, L, 0.02, 10, taps.astype(np.complex64), True)
+    exp2, etaps2 = c_oracle.nlms(ref, srv, L, 0.02, 10, taps.astype(np.complex64))
+    assert rel_err(out2, exp2) < TOL and rel_err(taps2, etaps2) < TOL
+
+
+def test_nlms_documented_tap_limit():
+    from passiveradar_amd.clutter_removal import NLMS_filter
+    ref, srv = scene.make_scene(9000, 1e4, 50, 5)
+    with pytest.raises(NotImplementedError):
+        NLMS_filter(ref, srv, 8190, 0.05, 10)                   # T = 8200 > 8192
 
 
 @pytest.mark.parametrize("tail", [1, 5, 9, 10])
