@@ -20,7 +20,7 @@
 // takes any length, :189-249) a stream is ONE workgroup of NW wavefronts: consecutive tap ranges of T/NW taps each, one
 // shared LDS window, and per step one exchange of the NW partial sums of w^H u through LDS (double-buffered slots, one
 // workgroup barrier per step; every wavefront adds the partials in the same order, so all of them see the same error
-// sample).  Each wavefront slides the energy of the WHOLE tap window itself (two more broadcast LDS reads per step).
+// sample).  The step sizes of a window come from the first wavefront's prepass.
 #include "common.h"
 
 struct NlmsArgs {
@@ -112,9 +112,11 @@ __global__ __launch_bounds__(64 * (NW > 1 ? NW : MAXW)) void nlms_kernel(NlmsArg
     const int KT = a.kt;
     const int wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     constexpr int WIN = 64 * TPL * NW;                  // >= T: the window of all the stream's taps
-    float2* Rw = reinterpret_cast<float2*>(smem_raw) + (NW > 1 ? (size_t)0 : (size_t)wave_id * (2 * KT + WIN));   // KT + WIN : ref window
-    float2* D = Rw + KT + WIN;                          // KT : srv in, error out
-    float2* S = D + KT;                                 // NW > 1: partial sums of w^H u, [step parity][wavefront]
+    // per stream: KT + WIN float2 (reference window), KT float2 (srv in, error out), KT float (step sizes mu / u^H u)
+    float2* Rw = reinterpret_cast<float2*>(smem_raw) + (NW > 1 ? (size_t)0 : (size_t)wave_id * (2 * KT + WIN + KT / 2));
+    float2* D = Rw + KT + WIN;
+    float* Sa = reinterpret_cast<float*>(D + KT);
+    float2* S = D + KT + KT / 2;                        // NW > 1: partial sums of w^H u, [step parity][wavefront]
     const int lane = threadIdx.x & 63;
     const int tid = NW > 1 ? (int)threadIdx.x : lane;   // index and stride of the loops that stage / drain the LDS windows
     constexpr int NT = 64 * NW;
@@ -166,8 +168,12 @@ __global__ __launch_bounds__(64 * (NW > 1 ? NW : MAXW)) void nlms_kernel(NlmsArg
         // slide does when the reference level falls sharply inside the tap window (a 50 dB drop leaves an energy
         // that is mostly rounding error, mu / en then blows up); the squares of float32 samples are exact in
         // double and the running sum is good to 1e-16 of the largest energy seen, so the slid value equals the
-        // reference's per-step sum to float32 accuracy whatever the input does (four f64 FMAs per step).
-        double energy;
+        // reference's per-step sum to float32 accuracy whatever the input does.
+        // The slide does not depend on the taps, so it is not part of the recursion: all KT energies of the window are made
+        // here, 64 lanes wide (a run of KT / 64 steps per lane, one exclusive scan of the lanes' totals in double), and the
+        // step loop reads its step size mu / (u^H u) from LDS -- one broadcast ds_read_b32 where the sequential slide
+        // was two ds_read_b64, four conversions, four f64 FMAs, a conversion back and the reciprocal (12 of ~105
+        // instructions per step at T = 1034).
         v2f P[TPL];                                    // the lane's samples, rotating: tap t of step j is P[(t - j) mod TPL]
         {
             double e0 = 0.0;
@@ -178,26 +184,54 @@ __global__ __launch_bounds__(64 * (NW > 1 ? NW : MAXW)) void nlms_kernel(NlmsArg
                 if (NW == 1) e0 = fma((double)v.x, (double)v.x, fma((double)v.y, (double)v.y, e0));
                 P[t] = v2f{v.x, v.y};
             }
-            if (NW > 1) {                              // the energy of ALL T taps, summed by every wavefront in the same order
-                for (int i = lane; i < T; i += 64) {
-                    const float2 v = Rw[WIN - 1 - i];
-                    e0 = fma((double)v.x, (double)v.x, fma((double)v.y, (double)v.y, e0));
+            if (NW == 1 || wave_id == 0) {
+                if (NW > 1) {                          // the energy of ALL T taps
+                    for (int i = lane; i < T; i += 64) {
+                        const float2 v = Rw[WIN - 1 - i];
+                        e0 = fma((double)v.x, (double)v.x, fma((double)v.y, (double)v.y, e0));
+                    }
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) e0 += __shfl_xor(e0, m, 64);
+                // E(kk) = E(0) + sum_{m < kk} delta(m), delta(m) = |Rw[m + WIN]|^2 - |Rw[m + WIN - T]|^2
+                const int Q = KT >> 6;                 // steps per lane (KT is a multiple of 64)
+                double run = 0.0;
+                for (int q = 0; q < Q; ++q) {
+                    const int m = lane * Q + q;
+                    const float2 vi = Rw[m + WIN], vo = Rw[m + WIN - T];
+                    run = fma((double)vi.x, (double)vi.x, run);
+                    run = fma((double)vi.y, (double)vi.y, run);
+                    run = fma(-(double)vo.x, (double)vo.x, run);
+                    run = fma(-(double)vo.y, (double)vo.y, run);
+                }
+                double incl = run;                     // inclusive scan of the lanes' totals
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const double up = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += up;
+                }
+                double e = e0 + (incl - run);          // E at the lane's first step
+                for (int q = 0; q < Q; ++q) {
+                    const int m = lane * Q + q;
+                    Sa[m] = a.mu * __builtin_amdgcn_rcpf((float)e);       // hardware reciprocal (1 ulp): the step size is a tuning
+                    const float2 vi = Rw[m + WIN], vo = Rw[m + WIN - T];  // constant, its last bit is not the reference's either
+                    e = fma((double)vi.x, (double)vi.x, e);
+                    e = fma((double)vi.y, (double)vi.y, e);
+                    e = fma(-(double)vo.x, (double)vo.x, e);
+                    e = fma(-(double)vo.y, (double)vo.y, e);
                 }
             }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) e0 += __shfl_xor(e0, m, 64);
-            energy = e0;
+            team_fence();
         }
         for (int kk0 = 0; kk0 < cnt; kk0 += TPL) {
 #pragma unroll
             for (int j = 0; j < TPL; ++j) {
                 const int kk = kk0 + j;
                 if (kk < cnt) {                        // uniform (no break: the unrolled body keeps its constant register indices)
-                    // the sample that enters tap 0 at the next step (also the one entering the energy window), the one leaving it
-                    // (NW > 1: vin enters THIS wavefront's first tap, vtot the stream's)
-                    const float2 vin = Rw[kk + WIN - oq], vout = Rw[kk + WIN - T];
-                    const float2 vtot = NW > 1 ? Rw[kk + WIN] : vin;
+                    // the sample that enters this wavefront's first tap at the next step, the surveillance sample, the step size
+                    const float2 vin = Rw[kk + WIN - oq];
                     const float2 d = D[kk];
+                    const float sk = Sa[kk];
                     // conj(w) . u on packed FMAs, two chains opened by a product (no zeroed accumulators to set up)
                     v2f acc0 = pk_cmul_conj(w[0], P[(0 - j + TPL) % TPL]);
                     v2f acc1 = TPL > 1 ? pk_cmul_conj(w[1 % TPL], P[(1 - j + TPL) % TPL]) : v2f{0.f, 0.f};
@@ -218,18 +252,8 @@ __global__ __launch_bounds__(64 * (NW > 1 ? NW : MAXW)) void nlms_kernel(NlmsArg
                         yr = sr;
                         yi = si;
                     }
-                    const float en = (float)energy;
-                    {
-                        const double ix = (double)vtot.x, iy = (double)vtot.y, ox = (double)vout.x, oy = (double)vout.y;
-                        energy = fma(ix, ix, energy);
-                        energy = fma(iy, iy, energy);
-                        energy = fma(-ox, ox, energy);
-                        energy = fma(-oy, oy, energy);
-                    }
                     const float er = d.x - yr, ei = d.y - yi;
-                    // coefficient mu conj(e) / (u^H u): hardware reciprocal (1 ulp) instead of the twelve-instruction IEEE
-                    // division -- the step size is a tuning constant, its last bit is not the reference's either
-                    const float s = a.mu * __builtin_amdgcn_rcpf(en);
+                    const float s = sk;                 // mu / (u^H u)
                     const v2f c = {er * s, ei * s};
 #pragma unroll
                     for (int t = 0; t < TPL; ++t) pk_cmac_bconj(w[t], P[(t - j + TPL) % TPL], c);
@@ -306,9 +330,10 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
         // one stream per workgroup of nwave wavefronts; two workgroups per CU where the window allows it
         int kt = 1024;
         const size_t win = (size_t)64 * tpl * nwave;
-        while (kt > 128 && (2 * (size_t)kt + win + 2 * nwave) * sizeof(float2) > 80 * 1024) kt >>= 1;
+        auto team_lds = [&](int k) { return (2 * (size_t)k + win + k / 2 + 2 * nwave) * sizeof(float2); };
+        while (kt > 128 && team_lds(kt) > 80 * 1024) kt >>= 1;
         a.kt = kt;
-        const size_t lds = (2 * (size_t)kt + win + 2 * nwave) * sizeof(float2);
+        const size_t lds = team_lds(kt);
 #define PRC_NLMS_TEAM_CASE(G)                                                                   \
     case G: {                                                                                   \
         const void* fn = nwave == 2 ? reinterpret_cast<const void*>(&nlms_kernel<G, 1, 2>)      \
@@ -329,10 +354,13 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
 #undef PRC_NLMS_TEAM_CASE
         return PRC_EUNSUPPORTED;
     }
+    // steps per staged window: a multiple of 64 (the energy prepass gives every lane a run of kt / 64 steps); per stream
+    // kt + 64 tpl reference samples, kt surveillance / error samples (complex64) and kt step sizes (float32)
+    auto wave_lds = [&](int k) { return (size_t)nw * (2 * (size_t)k + 64 * tpl + k / 2) * sizeof(float2); };
     int kt = 1024;
-    while (kt > 64 && (size_t)nw * (2 * kt + 64 * tpl) * sizeof(float2) > lds_cu) kt >>= 1;
+    for (const int k : {1024, 768, 512, 384, 256, 192, 128, 64}) { kt = k; if (wave_lds(k) <= lds_cu) break; }
     a.kt = kt;
-    size_t lds = (size_t)nw * (2 * kt + 64 * tpl) * sizeof(float2);
+    size_t lds = wave_lds(kt);
     PRC_REQUIRE(lds <= lds_cu, PRC_EUNSUPPORTED, "prc_nlms_execute: %d taps do not fit the LDS window", T);
     if (lds < 84 * 1024) lds = 84 * 1024;              // more than half a CU's LDS: one workgroup per CU
     const int grid = (int)ceil_div64(nstreams, nw);
