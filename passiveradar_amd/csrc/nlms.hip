@@ -77,8 +77,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // Both sums of a step (re, im of conj(w).u) in ONE reduction: v_permlane32_swap puts the real partials of the upper half
-// next to the imaginary partials of the lower half, one add folds the halves, four DPP adds reduce the 16-lane rows, and
-// the four row sums are read back -- 12 instructions where two separate all-lane sums took 22.
+// next to the imaginary partials of the lower half, one add folds the halves, four DPP adds reduce the 16-lane rows (every
+// lane of a row then holds the row sum), row_bcast:15 adds row 0 into row 1 and row 2 into row 3, and lanes 31 / 63 are
+// read back -- 9 instructions where two separate all-lane sums took 22.
 __device__ __forceinline__ void wave_allsum2(float& yr, float& yi) {
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_int(yr), __float_as_int(yi), false, false);
     float v = __int_as_float(sw[0]) + __int_as_float(sw[1]);     // lanes 0-31: re(l) + re(l+32); lanes 32-63: im
@@ -86,12 +87,10 @@ __device__ __forceinline__ void wave_allsum2(float& yr, float& yi) {
     v += dpp_f(v, 1);
     v += dpp_f(v, 2);
     v += dpp_f(v, 3);
-    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    yr = a + b;
-    yi = c + d;
+    // rows 1 and 3 (row_mask 0xA) receive lane 15 of the row before them; rows 0 and 2 add zero
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    yr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    yi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 // lane l <- lane l-1 across the whole wavefront; lane 0 keeps `lane0`
 __device__ __forceinline__ float wave_shr1(float lane0, float src) {
