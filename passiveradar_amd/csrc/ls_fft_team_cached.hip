@@ -11,9 +11,11 @@
 // correlation inputs, where the slot origin ext = T - 1 rounded up to 16 samples (ltc_piece: pieces then start on
 // 128-byte lines; the extra history slots are harmless to the overlap-save FIR and to the lags 0 .. T-1).  Compiled with one exchange buffer (FT_NBUF = 1, Makefile): 36 KB of exchange + 32 KB of
 // per-thread spectrum (autocorrelation accumulator / tap spectrum) = 68 KB per workgroup, two workgroups per CU.
-// This file: the fused FIR + correlation kernel, with the T2 twiddles factored (FT_TW2_FACTORED: 2 VGPRs instead of 32 --
-// with 32 it spills and runs 28 % slower); the first-bin kernel sits in ls_fft_team_corr_cached.hip, which keeps them in
-// registers (it is VALU-bound and 13 % faster that way).  Both measured with tools/ab_ls_team.sh.
+// This file: the fused FIR + correlation kernel; the first-bin kernel sits in ls_fft_team_corr_cached.hip (its own unit so
+// that the two can be built with different FT_* options: A/B runs with tools/build_variant.sh + tools/ab_ls_team.sh).  Both
+// keep the T2 twiddles in registers: the first-bin kernel is VALU-bound (13 % slower with the factored form), and the fused
+// kernel has the registers since the next block's prefetch moved behind the inverse transform (with the prefetch in front of
+// it the twiddles spilled: 2.02 ms; factored twiddles 1.53-1.55 ms; this arrangement 1.49 ms per 256 chunk-bins).
 #include "ls_team_cached.h"
 #include <stdlib.h>
 
@@ -91,7 +93,9 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_fused_cached_team_kernel(LsF
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[r] = cmul(xc[r], Hs[FT_THREADS * r]);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef LTC_EARLY_PREFETCH    // A/B: the next block's loads issued before the inverse transform (32 more VGPRs live through it)
         issue_x(p + pstep < pend ? p + pstep : nblocks);
+#endif
         {
 #ifdef LTC_EXP_NOLOAD
 #pragma unroll
@@ -154,6 +158,14 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_fused_cached_team_kernel(LsF
             const bool in = idx >= ext && idx < ext + cnt;
             y[r] = in ? o : make_float2(0.f, 0.f);
         }
+#ifndef LTC_EARLY_PREFETCH
+        // the next block's spectrum flies under the forward transform: issued here and not before the inverse, its 32 landing
+        // registers are free during the inverse, which is what lets the T2 twiddles stay in registers without spills
+        // (measured: early prefetch + factored twiddles 1.53-1.55 ms, this 1.49 ms per 256 chunk-bins)
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(p + pstep < pend ? p + pstep : nblocks);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (a.has_next) {
 #ifndef LTC_EXP_NOFFT
             ft4096_fwd<1>(y, f);

@@ -1,6 +1,6 @@
 // First-bin kernel of the cached-spectrum chain on the 4096-point team transform (see ls_fft_team_cached.hip for the
-// chain and the slot conventions).  Three forward transforms per piece make it VALU-bound: compiled with the T2 twiddles in
-// registers (FT_NBUF = 1 only, Makefile).
+// chain and the slot conventions).  Three forward transforms per piece make it VALU-bound: T2 twiddles in registers,
+// one exchange buffer (FT_NBUF = 1, Makefile).
 #include "ls_team_cached.h"
 
 // First bin of the chain: X_p = FFT(rho block p) -> spectrum cache; partial sums of the autocorrelation of rho and of
