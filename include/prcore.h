@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRC_VERSION 300
+#define PRC_VERSION 310   /* 310: prc_ls_desc.method = 4 (cached chain on 4096-point transforms), NLMS up to 8192 taps */
 
 typedef enum prc_status {
     PRC_OK = 0,
