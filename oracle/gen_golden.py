@@ -159,6 +159,18 @@ def nlms_cases():
     save("nlms_t74", ref=a, srv=s, L=70, mu=0.08, peek=4, out=o3, taps=t3)
 
 
+def nlms_long_cases():
+    """filters longer than the 2048 taps of one wavefront (two / four wavefronts per stream on the device): the reference's own
+    NLMS_filter on a short seeded scene; inputs are regenerated from the seed, the full output and the final taps are stored"""
+    print("NLMS, 2110 and 4110 taps")
+    for L in (2100, 4100):
+        n = L + 10 + 1300
+        seed = 7000 + L
+        a, s = scene.make_scene(n, 1e4, 50, seed)
+        o, t = ref_cr.NLMS_filter(a, s, L, 0.05, returnFilter=True)
+        save(f"nlms_t{L + 10}", seed=seed, N=n, L=L, fs=1e4, scene_R=50, mu=0.05, peek=10, out=o, taps=t)
+
+
 def config_cases():
     print("getConfiguration")
     import tempfile
@@ -483,6 +495,7 @@ if __name__ == "__main__":
         helper_cases()
         ls_cases()
         nlms_cases()
+        nlms_long_cases()
         config_cases()
         stream_case()
         frontend_case()

@@ -365,6 +365,16 @@ def test_nlms_beyond_one_wavefront(L):
     assert rel_err(out2, exp2) < TOL and rel_err(taps2, etaps2) < TOL
 
 
+@pytest.mark.parametrize("T", [2110, 4110])
+def test_nlms_long_filters_vs_reference_golden(T):
+    """two / four wavefronts per stream against the REFERENCE's own output (oracle/gen_golden.py::nlms_long_cases)"""
+    from passiveradar_amd.clutter_removal import NLMS_filter
+    g = load_golden(f"nlms_t{T}")
+    a, s = scene.make_scene(int(g["N"]), float(g["fs"]), int(g["scene_R"]), int(g["seed"]))
+    out, taps = NLMS_filter(a, s, int(g["L"]), float(g["mu"]), int(g["peek"]), None, True)
+    assert rel_err(out, g["out"]) < TOL and rel_err(taps, g["taps"]) < TOL
+
+
 def test_nlms_documented_tap_limit():
     from passiveradar_amd.clutter_removal import NLMS_filter
     ref, srv = scene.make_scene(9000, 1e4, 50, 5)

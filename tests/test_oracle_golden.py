@@ -119,6 +119,21 @@ def test_nlms():
     assert not out[:0].any() and not g["out"][:L].any() and not g["out"][-pk:].any()
 
 
+@pytest.mark.parametrize("T", [2110, 4110])
+def test_nlms_long_filters_vs_reference(T):
+    """the reference's own NLMS_filter at filter lengths beyond one wavefront's 2048 taps (inputs from the seed): both
+    restatements -- they are what the GPU kernels with two / four wavefronts per stream are checked against"""
+    from oracle import c_oracle
+    from passiveradar_amd import scene
+    g = load_golden(f"nlms_t{T}")
+    a, s = scene.make_scene(int(g["N"]), float(g["fs"]), int(g["scene_R"]), int(g["seed"]))
+    L, mu, pk = int(g["L"]), float(g["mu"]), int(g["peek"])
+    out, taps = O.NLMS_filter(a, s, L, mu, pk, None, True)
+    assert rel_err(out, g["out"]) < 1e-5 and rel_err(taps, g["taps"]) < 1e-5
+    out, taps = c_oracle.nlms(a, s, L, mu, pk)
+    assert rel_err(out, g["out"]) < 1e-5 and rel_err(taps, g["taps"]) < 1e-5
+
+
 def test_stream_pipeline():
     g = load_golden("stream")
     C, R, F = int(g["C"]), int(g["R"]), int(g["F"])
