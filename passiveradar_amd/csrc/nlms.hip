@@ -20,8 +20,10 @@
 // takes any length, :189-249) a stream is ONE workgroup of NW wavefronts: consecutive tap ranges of T/NW taps each, one
 // shared LDS window, and per step one exchange of the NW partial sums of w^H u through LDS (double-buffered slots, one
 // workgroup barrier per step; every wavefront adds the partials in the same order, so all of them see the same error
-// sample).  The step sizes of a window come from the first wavefront's prepass.
+// sample).  The step sizes of a window come from the first wavefront's prepass.  The split is for register space only: at
+// T = 1034 a stream alone steps in 253 ns on one wavefront, 334 on two, 302 on four (tools/nlms_waves_probe.py).
 #include "common.h"
+#include <stdlib.h>
 
 struct NlmsArgs {
     const float2* ref;
@@ -295,7 +297,12 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
     const int T = filter_len + peek;
     PRC_REQUIRE(T <= 8192, PRC_EUNSUPPORTED,
                 "prc_nlms_execute: %d taps exceed the four-wavefront kernel (max 8192)", T);
-    const int nwave = T <= 2048 ? 1 : (T <= 4096 ? 2 : 4);       // wavefronts per stream
+    int nwave = T <= 2048 ? 1 : (T <= 4096 ? 2 : 4);             // wavefronts per stream
+    // experiment knob (tools/nlms_waves_probe.py): split a config-3 sized filter (T = 1034) over 2 or 4 wavefronts too
+    if (const char* e = getenv("PRC_NLMS_WAVES")) {
+        const int v = atoi(e);
+        if ((v == 2 || v == 4) && v > nwave && T == 1034) nwave = v;
+    }
     const int tpl = ((T + nwave - 1) / nwave + 63) / 64;          // taps per lane: <= 32
     NlmsArgs a;
     a.ref = (const float2*)ref;
@@ -344,6 +351,7 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
         return PRC_OK;                                                                          \
     }
         switch (tpl) {
+            PRC_NLMS_TEAM_CASE(5) PRC_NLMS_TEAM_CASE(9)          // T = 1034 on four / two wavefronts (the experiment knob only)
             PRC_NLMS_TEAM_CASE(17) PRC_NLMS_TEAM_CASE(18) PRC_NLMS_TEAM_CASE(19) PRC_NLMS_TEAM_CASE(20)
             PRC_NLMS_TEAM_CASE(21) PRC_NLMS_TEAM_CASE(22) PRC_NLMS_TEAM_CASE(23) PRC_NLMS_TEAM_CASE(24)
             PRC_NLMS_TEAM_CASE(25) PRC_NLMS_TEAM_CASE(26) PRC_NLMS_TEAM_CASE(27) PRC_NLMS_TEAM_CASE(28)
