@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define PRC_VERSION 310   /* 310: prc_ls_desc.method = 4 (cached chain on 4096-point transforms), NLMS up to 8192 taps */
+#define PRC_VERSION 400   /* 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
+                             prc_comm_count; 310: prc_ls_desc.method = 4, NLMS up to 8192 taps */
 
 typedef enum prc_status {
     PRC_OK = 0,
@@ -56,6 +57,25 @@ int prc_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stre
 int prc_memset(void* dptr, int value, size_t bytes, void* stream);
 int prc_stream_sync(void* stream);
 
+/* Tuning options.  The library reads NO environment variables: kernel-selection knobs are fields of the plan
+ * descriptors (method, doppler, multi) or these process-wide options, which a plan copies ONCE, at creation (a later
+ * prc_set_option never changes an existing plan); prc_nlms_execute, which has no plan, reads PRC_OPT_NLMS_WAVES per call. */
+typedef enum prc_option {
+    PRC_OPT_CAF_MULTI_MODE = 0,   /* what prc_caf_desc.multi = PRC_CAF_MULTI_AUTO resolves to; default AUTO = the library's
+                                     measured choice                                                                      */
+    PRC_OPT_CAF_GROUP_MB = 1,     /* > 0: surfaces per segment/Doppler round of prc_caf_execute sized to this many MiB of
+                                     slow-time buffer; default 0 = the whole batch in one round                           */
+    PRC_OPT_LS_TEAM_PIECES = 2,   /* pieces per team of the 4096-point LS chain (default 32)                              */
+    PRC_OPT_LS_TEAM_ALIGN = 3,    /* 1 (default): pieces of the 4096-point LS chain start on 128-byte lines; 0: E = T - 1  */
+    PRC_OPT_NLMS_WAVES = 4,       /* 0 (default): wavefronts per NLMS stream from the tap count; 2 / 4: split a stream
+                                     that would fit one wavefront over 2 / 4 (latency experiments)                        */
+    PRC_OPT_LS_CACHE_LIMIT_MB = 5,/* > 0: an LS plan does not allocate a spectrum cache larger than this many MiB and runs
+                                     the recomputing / per-bin kernels instead; default 0 = no limit                      */
+    PRC_OPT_COUNT_ = 6
+} prc_option;
+int prc_set_option(int32_t option, int64_t value);     /* PRC_EINVAL for an unknown option or a value out of range */
+int prc_get_option(int32_t option, int64_t* value);
+
 /* ---- cross-ambiguity surface: fast_xambg (range_doppler_processing.py:12-90) -------- */
 typedef enum prc_caf_method {
     PRC_CAF_AUTO = 0,
@@ -74,6 +94,15 @@ typedef enum prc_doppler_method {
                                into the store: the surface is read once and written once    */
 } prc_doppler_method;
 
+/* How prc_caf_execute_multi runs several reference channels against one surveillance channel */
+typedef enum prc_caf_multi_mode {
+    PRC_CAF_MULTI_AUTO = 0,   /* the library's choice (PRC_OPT_CAF_MULTI_MODE overrides what AUTO means)               */
+    PRC_CAF_MULTI_TURNS = 1,  /* one single-reference pass per illuminator (any method)                                */
+    PRC_CAF_MULTI_SHARED = 2, /* 4096-point method: the surveillance pieces of a segment are transformed once for ALL
+                                 illuminators (two wavefronts per SIMD)                                                */
+    PRC_CAF_MULTI_PAIRS = 3   /* 4096-point method: once per PAIR of illuminators (three wavefronts per SIMD)           */
+} prc_caf_multi_mode;
+
 typedef struct prc_caf_desc {
     int64_t n;             /* samples per CPI after zero padding = inputLen (:52-55)         */
     int32_t range_bins;    /* rangeBins; the surface has range_bins+1 columns (:64)          */
@@ -83,6 +112,8 @@ typedef struct prc_caf_desc {
     int32_t doppler;       /* prc_doppler_method                                             */
     int32_t ntaps;         /* 0: boxcar ones(q+1) (shortFilt=True, :72); else length of taps */
     const float* taps_host;/* HOST pointer, copied at plan creation (shortFilt=False, :76)   */
+    int32_t multi;         /* prc_caf_multi_mode of prc_caf_execute_multi (0 = AUTO)         */
+    int32_t reserved;      /* 0                                                              */
 } prc_caf_desc;
 
 typedef struct prc_caf_plan prc_caf_plan;
@@ -92,6 +123,8 @@ int prc_caf_plan_destroy(prc_caf_plan* plan);
 /* Which kernels the plan resolved AUTO to (prc_caf_method / prc_doppler_method values). */
 int prc_caf_plan_info(const prc_caf_plan* plan, int32_t* method, int32_t* doppler,
                       int64_t* workspace_bytes);
+/* The prc_caf_multi_mode the plan resolved AUTO to (TURNS / SHARED / PAIRS). */
+int prc_caf_plan_multi_mode(const prc_caf_plan* plan, int32_t* multi);
 
 /* out[f][k] for each frame: complex64 [nframes][freq_bins][range_bins+1], C order; frame b
  * reads ref/srv at element offset b*frame_stride (frame_stride = n for dense batches, = n/2
@@ -105,10 +138,11 @@ int prc_caf_execute(prc_caf_plan* plan, const void* ref, const void* srv, int64_
 /* fast_xambg for nref (<= 8) reference channels against ONE surveillance channel in one call -- a multi-illuminator
  * frame (range_doppler_processing.py:12-90 once per pair; :81-86 is the per-pair unit): outs_host[i] receives what
  * prc_caf_execute(plan, refs_host[i], srv, ...) would write.  refs_host / outs_host are HOST arrays of nref DEVICE
- * pointers.  nframes * nref surfaces must fit the plan's max_frames.  By default the illuminators take turns through
- * the single-reference kernels (measured fastest on MI355X); with PRC_CAF_MULTI_MODE=1 in the environment, the
- * 4096-point method and segments of at most two pieces (wide range spans: BASELINE configs 3 and 5) the surveillance
- * pieces are transformed once per segment for all illuminators (same results to the order of two sums). */
+ * pointers.  nframes * nref surfaces must fit the plan's max_frames.  prc_caf_desc.multi selects how (prc_caf_multi_mode):
+ * the illuminators take turns through the single-reference kernels, or -- 4096-point method, segments of at most two
+ * pieces (wide range spans: BASELINE configs 3 and 5) -- the surveillance pieces of a segment are transformed once for all
+ * illuminators or once per pair (same results to the order of two sums).  A mode the plan's shape does not support falls
+ * back to TURNS. */
 int prc_caf_execute_multi(prc_caf_plan* plan, const void* const* refs_host, int32_t nref, const void* srv,
                           int64_t frame_stride, int64_t n_valid, const float* window, void* const* outs_host,
                           int32_t nframes, void* stream);
@@ -266,6 +300,9 @@ typedef struct prc_comm prc_comm;
 int prc_comm_unique_id(void* id_host);                       /* HOST buffer of PRC_COMM_ID_BYTES      */
 int prc_comm_create(prc_comm** comm, const void* id_host, int32_t rank, int32_t world);
 int prc_comm_rccl_version(int32_t* version);                  /* ncclGetVersion of the RCCL that was bound      */
+/* what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank): the number of ranks it connected and
+ * this process's rank among them -- a bench line can show that N ranks really met */
+int prc_comm_count(const prc_comm* comm, int32_t* nranks, int32_t* rank);
 int prc_comm_destroy(prc_comm* comm);
 /* send: this rank's frames_per_rank_host[rank] frames of frame_elems complex64 (DEVICE).  recv (root
  * only, DEVICE): sum(frames_per_rank_host) frames, rank r's block at frame offset sum_{q<r}.  Blocks may

@@ -18,6 +18,10 @@ LIB_PATH = os.environ.get("PRCORE_LIB", os.path.join(_HERE, "libprcore.so"))   #
 PRC_OK, PRC_EINVAL, PRC_ESHAPE, PRC_EHIP, PRC_EROCFFT, PRC_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 CAF_AUTO, CAF_DIRECT, CAF_FFT, CAF_FFT4096 = 0, 1, 2, 3
 DOPPLER_AUTO, DOPPLER_ROCFFT, DOPPLER_COLUMN = 0, 1, 2
+CAF_MULTI_AUTO, CAF_MULTI_TURNS, CAF_MULTI_SHARED, CAF_MULTI_PAIRS = 0, 1, 2, 3
+CAF_MULTI_MODES = {"auto": CAF_MULTI_AUTO, "turns": CAF_MULTI_TURNS, "shared": CAF_MULTI_SHARED, "pairs": CAF_MULTI_PAIRS}
+# prc_option
+OPT_CAF_MULTI_MODE, OPT_CAF_GROUP_MB, OPT_LS_TEAM_PIECES, OPT_LS_TEAM_ALIGN, OPT_NLMS_WAVES, OPT_LS_CACHE_LIMIT_MB = range(6)
 CAF_MAX_REFS = 8
 COMM_ID_BYTES = 128
 
@@ -31,7 +35,8 @@ class PrcoreError(RuntimeError):
 class CafDesc(C.Structure):
     _fields_ = [("n", C.c_int64), ("range_bins", C.c_int32), ("freq_bins", C.c_int32),
                 ("max_frames", C.c_int32), ("method", C.c_int32), ("doppler", C.c_int32),
-                ("ntaps", C.c_int32), ("taps_host", C.POINTER(C.c_float))]
+                ("ntaps", C.c_int32), ("taps_host", C.POINTER(C.c_float)), ("multi", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class LsDesc(C.Structure):
@@ -68,6 +73,9 @@ _SIGNATURES = {
     "prc_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "prc_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "prc_stream_sync": (C.c_int, [C.c_void_p]),
+    "prc_set_option": (C.c_int, [C.c_int32, C.c_int64]),
+    "prc_get_option": (C.c_int, [C.c_int32, C.POINTER(C.c_int64)]),
+    "prc_caf_plan_multi_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "prc_caf_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(CafDesc)]),
     "prc_caf_plan_destroy": (C.c_int, [C.c_void_p]),
     "prc_caf_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -110,6 +118,7 @@ _SIGNATURES = {
     "prc_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int32, C.c_int32]),
     "prc_comm_destroy": (C.c_int, [C.c_void_p]),
     "prc_comm_rccl_version": (C.c_int, [C.POINTER(C.c_int32)]),
+    "prc_comm_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "prc_gather_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_void_p,
                                     C.c_int32, C.c_void_p]),
 }
@@ -186,6 +195,20 @@ def current_device():
     """the calling thread's current HIP device index (-1 without a GPU)"""
     d = C.c_int(-1)
     return d.value if lib().prc_get_device(C.byref(d)) == PRC_OK else -1
+
+
+def set_option(option, value):
+    """prc_set_option: process-wide tuning option (the library reads no environment variables); plans copy the options
+    that concern them when they are created.  Returns the previous value."""
+    old = get_option(option)
+    check(lib().prc_set_option(int(option), int(value)))
+    return old
+
+
+def get_option(option):
+    v = C.c_int64(0)
+    check(lib().prc_get_option(int(option), C.byref(v)))
+    return int(v.value)
 
 
 def rccl_version():

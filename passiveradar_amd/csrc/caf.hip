@@ -9,7 +9,6 @@
 // slow-time buffer is read back from the cache that took its writes rather than from HBM.
 #include "caf_internal.h"
 #include "doppler_col.h"
-#include <stdlib.h>
 #include <rocfft/rocfft.h>
 #include <vector>
 
@@ -30,6 +29,7 @@ struct prc_caf_plan {
     float2* d_y2 = nullptr;          // [j][k]-ordered slow-time buffer written row-wise by the segment kernels
     float2* d_dop_tw = nullptr;      // W_F^m table of the column-FFT Doppler kernel
     int group = 1;                   // surfaces per segment/Doppler round of prc_caf_execute
+    int multi = PRC_CAF_MULTI_TURNS; // resolved prc_caf_multi_mode of prc_caf_execute_multi
     size_t y_bytes = 0;
     rocfft_plan fft = nullptr;       // one batched plan for max_frames
     rocfft_execution_info info = nullptr;
@@ -84,28 +84,17 @@ static int build_rocfft(prc_caf_plan* p, int frames) {
     return PRC_OK;
 }
 
-// surfaces per segment/Doppler round: as many as keep the slow-time buffer inside the Infinity Cache next to
-// the inputs that stream through it (PRC_CAF_GROUP_MB overrides the budget; measured in DESIGN.md)
+// surfaces per segment/Doppler round.  Cache-sized groups (so that the slow-time buffer would be read back from the
+// Infinity Cache) lost to the tail effect of the smaller launches at every size measured: the
+// default is the whole batch; PRC_OPT_CAF_GROUP_MB, read here at plan creation, sizes the groups for A/B runs.
 static int pick_group(const prc_caf_desc* d) {
-    double mb = 1e9;
-    if (const char* e = getenv("PRC_CAF_GROUP_MB")) {
-        const double v = atof(e);
-        if (v > 0) mb = v;
-    }
+    const int64_t mb = prc_opt(PRC_OPT_CAF_GROUP_MB);
+    if (mb <= 0) return d->max_frames;
     const double surf = 8.0 * (double)d->freq_bins * (double)(d->range_bins + 1);
-    int g = (int)(mb * 1048576.0 / surf);
+    int g = (int)((double)mb * 1048576.0 / surf);
     if (g < 1) g = 1;
     if (g > d->max_frames) g = d->max_frames;
     return g;
-}
-
-// How prc_caf_execute_multi runs several illuminators: 0 = "turns", one single-reference pass per illuminator (three
-// wavefronts per SIMD; the default: measured fastest on MI355X); 1 = "shared", the kernel of
-// caf_fft_team_multi.hip that transforms the surveillance pieces once per segment for all illuminators (14 instead of 20
-// transforms per four-illuminator segment, but two wavefronts per SIMD).  PRC_CAF_MULTI_MODE overrides (A/B runs, tests).
-static int multi_mode() {
-    const char* e = getenv("PRC_CAF_MULTI_MODE");
-    return e ? atoi(e) : 0;
 }
 
 extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
@@ -150,13 +139,17 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
     }
     p->doppler = d->doppler;
     if (p->doppler == PRC_DOPPLER_AUTO)
-        p->doppler = dop_supported(d->freq_bins) ? PRC_DOPPLER_COLUMN : PRC_DOPPLER_ROCFFT;
-    if (p->doppler == PRC_DOPPLER_COLUMN && !dop_supported(d->freq_bins)) {
+        p->doppler = dop_supported(d->freq_bins, d->range_bins + 1) ? PRC_DOPPLER_COLUMN : PRC_DOPPLER_ROCFFT;
+    if (p->doppler == PRC_DOPPLER_COLUMN && !dop_supported(d->freq_bins, d->range_bins + 1)) {
         prc_set_error("prc_caf_plan_create: the column-FFT Doppler kernel takes freq_bins 256, 512, 1024, 2048, 4096 "
-                      "(got %d)", d->freq_bins);
+                      "and surfaces below 2^32 / 3 bytes (got %d x %d)", d->freq_bins, d->range_bins + 1);
         delete p;
         return PRC_EUNSUPPORTED;
     }
+    PRC_REQUIRE(d->multi >= PRC_CAF_MULTI_AUTO && d->multi <= PRC_CAF_MULTI_PAIRS, PRC_EINVAL,
+                "prc_caf_plan_create: unknown multi mode %d", d->multi);
+    p->multi = d->multi != PRC_CAF_MULTI_AUTO ? d->multi : (int)prc_opt(PRC_OPT_CAF_MULTI_MODE);
+    if (p->multi == PRC_CAF_MULTI_AUTO) p->multi = PRC_CAF_MULTI_DEFAULT;
     if (p->doppler != PRC_DOPPLER_ROCFFT && p->doppler != PRC_DOPPLER_COLUMN) {
         prc_set_error("prc_caf_plan_create: unknown Doppler method %d", d->doppler);
         delete p;
@@ -209,6 +202,12 @@ extern "C" int prc_caf_plan_destroy(prc_caf_plan* p) {
     if (p->d_y2) (void)hipFree(p->d_y2);
     if (p->d_dop_tw) (void)hipFree(p->d_dop_tw);
     delete p;
+    return PRC_OK;
+}
+
+extern "C" int prc_caf_plan_multi_mode(const prc_caf_plan* p, int32_t* multi) {
+    PRC_REQUIRE(p && multi, PRC_EINVAL, "prc_caf_plan_multi_mode: null argument");
+    *multi = p->multi;
     return PRC_OK;
 }
 
@@ -341,8 +340,8 @@ extern "C" int prc_caf_execute_multi(prc_caf_plan* p, const void* const* refs_ho
     std::lock_guard<std::mutex> lk(p->mtx);
     hipStream_t st = (hipStream_t)stream;
     const int64_t se = surf_elems(p);
-    const bool shared = multi_mode() == 1 && p->method == PRC_CAF_FFT4096 && p->doppler == PRC_DOPPLER_COLUMN && nref > 1 &&
-                        caf_team_multi_supported(p->desc.n, p->desc.range_bins, p->desc.freq_bins, p->ntaps, nref);
+    const bool shared = p->multi == PRC_CAF_MULTI_SHARED && p->method == PRC_CAF_FFT4096 && p->doppler == PRC_DOPPLER_COLUMN &&
+                        nref > 1 && caf_team_multi_supported(p->desc.n, p->desc.range_bins, p->desc.freq_bins, p->ntaps, nref);
     if (!shared) {
         // one pass per illuminator (any method): same results, nothing shared
         for (int i = 0; i < nref; ++i) {

@@ -91,7 +91,13 @@ void dop_make_table(float2* t, int F) {
     }
 }
 
-bool dop_supported(int F) { return F == 256 || F == 512 || F == 1024 || F == 2048 || F == 4096; }
+// the kernel addresses a whole surface through ONE 32-bit buffer descriptor: in-range offsets (< F * row_bytes) must stay
+// below its limit 0xFFFFFFF0 - 2 F row_bytes, i.e. 3 F cols 8 bytes < 2^32 (beyond that loads would read zeros and stores
+// would be dropped silently; AUTO takes the rocFFT path there)
+bool dop_supported(int F, int cols) {
+    if (!(F == 256 || F == 512 || F == 1024 || F == 2048 || F == 4096)) return false;
+    return 3.0 * (double)F * (double)cols * 8.0 < 4294967280.0;
+}
 
 template <int F>
 static int dop_launch_t(const float2* y, float2* out, const float2* tw, int cols, int nframes, hipStream_t stream) {

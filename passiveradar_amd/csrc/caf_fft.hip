@@ -173,21 +173,21 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
                 issue_u(n0, 8);
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    u[r] = r < 8 ? (HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r]) : make_float2(0.f, 0.f);
+                    u[r] = r < 8 ? (HAS_WIN ? cscale(un[r], wn[r]) : un[r]) : make_float2(0.f, 0.f);
                 __builtin_amdgcn_sched_barrier(0);
                 fft1024_fwd<8>(u, tile, tab, f);
             } else if (nz == 12) {
                 issue_u(n0, 12);
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    u[r] = r < 12 ? (HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r]) : make_float2(0.f, 0.f);
+                    u[r] = r < 12 ? (HAS_WIN ? cscale(un[r], wn[r]) : un[r]) : make_float2(0.f, 0.f);
                 __builtin_amdgcn_sched_barrier(0);
                 fft1024_fwd<12>(u, tile, tab, f);
             } else {
                 if (!PREFETCH) issue_u(n0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
+                    u[r] = HAS_WIN ? cscale(un[r], wn[r]) : un[r];
                 if (PREFETCH) issue_v(v[0], n0, cnt, lb0);
                 __builtin_amdgcn_sched_barrier(0);
                 fft1024_fwd(u, tile, tab, f);

@@ -44,6 +44,8 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 // hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that wants more than 64 KB of LDS: set once per (kernel, device),
 // not on every launch (util.hip)
 int prc_lds_optin(const void* kernel, int bytes);
+// current value of a prc_option (util.hip); plans read it once, at creation
+int64_t prc_opt(int option);
 
 // ---- device-side complex helpers (float2 = complex64, double2 = complex128) ----
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {

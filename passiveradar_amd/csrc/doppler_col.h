@@ -240,6 +240,6 @@ PRC_HD int dop_out_row_reg(int m) {
 
 // host side (caf_doppler.hip): W_F^m table, does the column kernel take this size, launch
 void dop_make_table(float2* host_tab, int F);
-bool dop_supported(int freq_bins);
+bool dop_supported(int freq_bins, int cols);
 int dop_launch(const float2* y, float2* out, const float2* tw, int freq_bins, int cols, int nframes,
                hipStream_t stream);

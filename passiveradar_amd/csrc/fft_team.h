@@ -31,6 +31,9 @@
 // buffer 0) must be separated by ft_team_sync().
 #pragma once
 #include "fft_wave.h"
+#ifdef FT_PK
+#include "fft_pk.h"
+#endif
 
 #define FT_P 4096
 #define FT_THREADS 256
@@ -112,6 +115,7 @@ __device__ __forceinline__ void ft_team_sync() { FT_BARRIER(); }
 
 // Forward FFT: time layout -> frequency layout.  CUR: buffer of the cross-wave exchange (alternate 0, 1, 0, ...).
 // NZ: registers x[NZ..15] are zero in every thread (a zero-padded piece of at most 256 NZ samples)
+#ifndef FT_PK
 template <int CUR, int NZ = 16>
 __device__ __forceinline__ void ft4096_fwd(float2 (&x)[16], const FtLane& f) {
     constexpr int T = (FT_NBUF == 2 ? CUR : 0) * FT_BUF, O = (FT_NBUF == 2 ? (CUR ^ 1) : 0) * FT_BUF;
@@ -139,8 +143,42 @@ __device__ __forceinline__ void ft4096_fwd(float2 (&x)[16], const FtLane& f) {
 #endif
     dft16<1>(x);
 }
+#else
+// FT_PK: the same stages on packed-f32 instructions (fft_pk.h): half the VALU instructions, identical roundings
+template <int CUR, int NZ = 16>
+__device__ __forceinline__ void ft4096_fwd(float2 (&xs)[16], const FtLane& f) {
+    constexpr int T = (FT_NBUF == 2 ? CUR : 0) * FT_BUF, O = (FT_NBUF == 2 ? (CUR ^ 1) : 0) * FT_BUF;
+    v2f x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = pk_from(xs[r]);
+    pk_dft16<1, NZ>(x);
+    pk_twiddle<1, 1>(x, [&](int k1) { return pk_from(f.tw1[16 * k1]); });
+#ifndef FT_EXP_NOX1
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) f.wr[T + k1] = pk_to(x[k1]);
+    FT_BARRIER();
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = pk_from(f.rdB[T + 16 * FT_PITCH * m]);
+    if (FT_NBUF == 1) FT_BARRIER();
+#endif
+    pk_dft16<1>(x);
+    pk_twiddle<1, 0>(x, [&](int k2) { return pk_from(ft_tw2(f, k2)); });
+#ifndef FT_EXP_NOX2
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) f.wr[O + k2] = pk_to(x[k2]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = pk_from(f.rdA[O + FT_PITCH * j]);
+    __builtin_amdgcn_wave_barrier();
+#endif
+    pk_dft16<1>(x);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xs[r] = pk_to(x[r]);
+}
+#endif
 
 // Inverse FFT (unnormalised): frequency layout -> time layout.  Both exchanges in buffer CUR.
+#ifndef FT_PK
 template <int CUR>
 __device__ __forceinline__ void ft4096_inv(float2 (&x)[16], const FtLane& f) {
     constexpr int T = (FT_NBUF == 2 ? CUR : 0) * FT_BUF;
@@ -169,6 +207,39 @@ __device__ __forceinline__ void ft4096_inv(float2 (&x)[16], const FtLane& f) {
     for (int k1 = 1; k1 < 16; ++k1) x[k1] = mul_tw<-1>(x[k1], f.tw1[16 * k1]);
     dft16<-1>(x);
 }
+#else
+template <int CUR>
+__device__ __forceinline__ void ft4096_inv(float2 (&xs)[16], const FtLane& f) {
+    constexpr int T = (FT_NBUF == 2 ? CUR : 0) * FT_BUF;
+    if (FT_NBUF == 2) FT_BARRIER();
+    v2f x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = pk_from(xs[r]);
+    pk_dft16<-1>(x);
+#ifndef FT_EXP_NOX2
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f.wr[T + j] = pk_to(x[j]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = pk_from(f.rdA[T + FT_PITCH * m]);
+    __builtin_amdgcn_wave_barrier();
+#endif
+    pk_twiddle<-1, 0>(x, [&](int k2) { return pk_from(ft_tw2(f, k2)); });
+    pk_dft16<-1>(x);
+#ifndef FT_EXP_NOX1
+#pragma unroll
+    for (int m = 0; m < 16; ++m) f.wr[T + m] = pk_to(x[m]);
+    FT_BARRIER();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) x[k1] = pk_from(f.rdB[T + 16 * FT_PITCH * k1]);
+    if (FT_NBUF == 1) FT_BARRIER();
+#endif
+    pk_twiddle<-1, 1>(x, [&](int k1) { return pk_from(f.tw1[16 * k1]); });
+    pk_dft16<-1>(x);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xs[r] = pk_to(x[r]);
+}
+#endif
 
 // Host side: FT_GTAB float2 (double-precision trig, rounded once); device copy per device.
 void ft_make_tables(float2* host_tab);

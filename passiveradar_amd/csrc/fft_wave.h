@@ -205,6 +205,7 @@ __device__ __forceinline__ void quad_dft4_bwd(float2 (&p)[16], const FftLane& f)
 
 // Forward FFT: natural (lane n2, reg n1) -> permuted frequency layout.
 // NZ: registers x[NZ..15] are zero in every lane (a zero-padded piece of at most 64 NZ samples)
+#ifndef FT_PK
 template <int NZ = 16>
 __device__ __forceinline__ void fft1024_fwd(float2 (&x)[16], float2* tile, const float2* tab,
                                             const FftLane& f) {
@@ -250,14 +251,23 @@ __device__ __forceinline__ void fft1024_inv(float2 (&x)[16], float2* tile, const
     for (int k1 = 1; k1 < 16; ++k1) x[k1] = mul_tw<-1>(x[k1], tab[k1 * 64 + f.lane]);
     dft16<-1>(x);
 }
+#endif   // the FT_PK forms of the two transforms: fft_wave_pk.h
 
 // w += conj(u) * v   (per register, same permuted layout on both sides)
+#ifndef FT_PK
 __device__ __forceinline__ void cmac_conj_a(float2& w, float2 u, float2 v) {
     w.x = fmaf(u.x, v.x, w.x);
     w.x = fmaf(u.y, v.y, w.x);
     w.y = fmaf(u.x, v.y, w.y);
     w.y = fmaf(-u.y, v.x, w.y);
 }
+// a * s, s real
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+#endif
 
 // Host side: build the FFTW_TABLE float2 twiddle table (double-precision trig, rounded once).
 void fftw_make_tables(float2* host_tab);
+
+#ifdef FT_PK
+#include "fft_wave_pk.h"
+#endif

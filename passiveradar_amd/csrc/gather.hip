@@ -33,6 +33,8 @@ struct RcclApi {
     nccl_result_t (*Recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(nccl_result_t) = nullptr;
     nccl_result_t (*GetVersion)(int*) = nullptr;
+    nccl_result_t (*CommCount)(nccl_comm_t, int*) = nullptr;
+    nccl_result_t (*CommUserRank)(nccl_comm_t, int*) = nullptr;
 };
 
 RcclApi g_rccl;
@@ -62,6 +64,8 @@ int rccl_load() {
     PRC_RCCL_SYM(Recv, "ncclRecv");
     PRC_RCCL_SYM(GetErrorString, "ncclGetErrorString");
     PRC_RCCL_SYM(GetVersion, "ncclGetVersion");
+    PRC_RCCL_SYM(CommCount, "ncclCommCount");
+    PRC_RCCL_SYM(CommUserRank, "ncclCommUserRank");
 #undef PRC_RCCL_SYM
     g_rccl = api;
     return PRC_OK;
@@ -125,6 +129,17 @@ extern "C" int prc_comm_create(prc_comm** comm, const void* id_host, int32_t ran
     return PRC_OK;
 }
 
+// what RCCL says about the communicator it built (not what the caller asked for)
+extern "C" int prc_comm_count(const prc_comm* c, int32_t* nranks, int32_t* rank) {
+    PRC_REQUIRE(c && c->comm, PRC_EINVAL, "prc_comm_count: null communicator");
+    int n = 0, r = 0;
+    PRC_RCCL(g_rccl.CommCount(c->comm, &n));
+    PRC_RCCL(g_rccl.CommUserRank(c->comm, &r));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    return PRC_OK;
+}
+
 extern "C" int prc_comm_destroy(prc_comm* c) {
     if (!c) return PRC_OK;
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
@@ -162,6 +177,9 @@ extern "C" int prc_gather_frames(prc_comm* c, const void* send, const int64_t* f
             PRC_RCCL(g_rccl.Send(send, (size_t)mine * floats_per_frame, NCCL_FLOAT32, root, c->comm, stream));
         return PRC_OK;
     }
+    int64_t total = 0;
+    for (int r = 0; r < c->world; ++r) total += frames_per_rank_host[r] > 0 ? frames_per_rank_host[r] : 0;
+    if (total == 0) return PRC_OK;                                    // an empty round: nothing to receive, nothing to check
     PRC_REQUIRE(recv, PRC_EINVAL, "prc_gather_frames: null receive buffer on the root");
     float* dst = (float*)recv;
     int64_t first = 0;

@@ -817,6 +817,7 @@ struct prc_ls_plan {
     int fft_waves;     // waves (1024-point kernels) or teams (4096-point kernels) per block in the FFT correlation kernel
     bool team = false; // the 4096-point team kernels of ls_fft_team.hip (770 .. 3073 taps, or method 4)
     bool team_chain = false;   // cached-spectrum chain on the 4096-point transform (ls_fft_team_cached.hip)
+    int team_piece = 0;        // its samples per piece, fixed here once (PRC_OPT_LS_TEAM_ALIGN at plan creation)
     float2* d_partial = nullptr;
     double2* d_taps = nullptr;
     double2* d_rhs = nullptr;      // right-hand sides of the per-bin Levinson solve, [block][T] (one element read per step)
@@ -895,7 +896,31 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
         }
         p->team = true;                         // beyond the 1024-point transform: 4096-point team kernels
     }
-    p->fft_waves = p->team_chain ? ls_team_chain_teams_per_block(d->n, T, d->max_blocks)
+    // Spectrum cache first: whether it can be had decides which kernels run, and with that the size of everything else.
+    // A cache that cannot be allocated (or that PRC_OPT_LS_CACHE_LIMIT_MB rules out) sends the 4096-point chain back to
+    // the 1024-point chain -- which recomputes the spectra when its own cache is missing too -- or, beyond 769 taps, to
+    // the per-bin team kernels.
+    const bool chain_ok = p->method == 2 && !d->circular;
+    const int64_t limit_mb = prc_opt(PRC_OPT_LS_CACHE_LIMIT_MB);
+    auto try_cache = [&](int64_t per_block) {
+        const size_t bytes = sizeof(float2) * (size_t)d->max_blocks * (size_t)per_block;
+        if (limit_mb > 0 && bytes > (size_t)limit_mb * 1048576u) return false;
+        if (hipMalloc(&p->d_cache, bytes) != hipSuccess) {
+            p->d_cache = nullptr;
+            (void)hipGetLastError();
+            return false;
+        }
+        return true;
+    };
+    if (p->team_chain) {
+        p->team_piece = ls_team_piece(T, (int)prc_opt(PRC_OPT_LS_TEAM_ALIGN));
+        if (!(chain_ok && d->method != 2 && try_cache(ls_team_cache_elems_per_block(d->n, p->team_piece)))) {
+            p->team_chain = false;
+            p->team = !ls_fft_supported(T);
+            p->team_piece = 0;
+        }
+    }
+    p->fft_waves = p->team_chain ? ls_team_chain_teams_per_block(d->n, p->team_piece, d->max_blocks, (int)prc_opt(PRC_OPT_LS_TEAM_PIECES))
                    : p->team     ? ls_team_teams_per_block(d->n, T) : ls_fft_waves_per_block(d->n, T);
     p->nblk = p->method == 2 ? p->fft_waves : (int)ceil_div64(d->n, LSC_BLK);
     hipError_t e = hipMalloc(&p->d_partial, sizeof(float2) * (size_t)d->max_blocks * p->nblk * 2 * T);
@@ -929,15 +954,8 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
         if (e == hipSuccess) e = hipMalloc(&p->d_taps_t, sizeof(double2) * (size_t)d->max_blocks * T);
         // auto / method 3: keep FFT(rho block) in an HBM spectrum cache instead of recomputing it per
         // bin (measured: the fused kernel is HBM-bound at 2 FFTs per block and VALU-bound at 3).  If the
-        // cache does not fit, the chain silently recomputes.
-        if (e == hipSuccess && d->method != 2) {
-            const int64_t per_block = p->team_chain ? ls_team_cache_elems_per_block(d->n, T) : ls_cache_elems_per_block(d->n, T);
-            if (hipMalloc(&p->d_cache, sizeof(float2) * (size_t)d->max_blocks * per_block) != hipSuccess) {
-                p->d_cache = nullptr;
-                (void)hipGetLastError();
-                if (p->team_chain) p->chain = false;    // the 4096-point chain has no recomputing form: per-bin kernels then
-            }
-        }
+        // cache does not fit, the chain silently recomputes.  (The 4096-point chain took its cache above.)
+        if (e == hipSuccess && d->method != 2 && !p->team_chain) (void)try_cache(ls_cache_elems_per_block(d->n, T));
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)ls_prepare_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
@@ -981,6 +999,7 @@ static void fill_xa(LsFftArgs& xa, prc_ls_plan* p, const void* ref, int64_t stri
     xa.T = p->T;
     xa.peek = p->desc.peek;
     xa.circular = p->desc.circular;
+    xa.piece = p->team_piece;           // 4096-point chain; the other kernels set their own
     xa.rot = pr.enabled;
     xa.pr = pr;
     xa.has_next = 0;

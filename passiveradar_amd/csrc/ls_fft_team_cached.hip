@@ -17,7 +17,6 @@
 // kernel has the registers since the next block's prefetch moved behind the inverse transform (with the prefetch in front of
 // it the twiddles spilled: 2.02 ms; factored twiddles 1.53-1.55 ms; this arrangement 1.49 ms per 256 chunk-bins).
 #include "ls_team_cached.h"
-#include <stdlib.h>
 
 // FIR of bin i fused with the cross-correlation of bin i+1: per piece the team reads X_p (cache, 32 KB) and the
 // surveillance piece once, writes the cleaned piece once and keeps it in registers as the next bin's correlation input
@@ -185,20 +184,19 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_fused_cached_team_kernel(LsF
     }
 }
 
-int64_t ls_team_cache_elems_per_block(int64_t n, int T) {
-    const int64_t B = ltc_piece(T);
-    return ((n + B - 1) / B) * FT_P;
+int ls_team_piece(int T, int align) { return ltc_piece(T, align); }
+
+int64_t ls_team_cache_elems_per_block(int64_t n, int piece) {
+    return ((n + piece - 1) / piece) * FT_P;
 }
 
-int ls_team_chain_teams_per_block(int64_t n, int T, int max_blocks) {
+int ls_team_chain_teams_per_block(int64_t n, int piece, int max_blocks, int per) {
     // ~32 pieces per team (the tap transform at the start and the inverse of the partial sums at the end are two
     // transforms without HBM traffic behind them; 8 / 16 / 32 / 64 measured 1.596 / 1.573 / 1.571 / 1.578 ms for the fused
     // kernel at 256 chunks), but at least ~2048 workgroups per launch (four rounds of the 512 resident ones) while a team
-    // keeps four pieces
-    int per = 32;
-    if (const char* e = getenv("PRC_LS_TEAM_PIECES")) { const int v = atoi(e); if (v > 0) per = v; }
-    const int64_t B = ltc_piece(T);
-    const int64_t pieces = (n + B - 1) / B;
+    // keeps four pieces.  per: PRC_OPT_LS_TEAM_PIECES as the plan read it.
+    if (per < 1) per = 32;
+    const int64_t pieces = (n + piece - 1) / piece;
     int64_t teams = pieces / per;
     int64_t fill = (2048 + max_blocks - 1) / max_blocks;
     if (fill > pieces / 4) fill = pieces / 4;

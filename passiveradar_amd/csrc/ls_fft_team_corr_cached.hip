@@ -32,7 +32,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_corr_cached_team_kernel(LsFf
     float2 xn[16];                                            // block of the next piece (prefetched)
     auto issue_x = [&](int p) {
         const bool live = p < npieces;
-        const int mstart = (live ? p * B : n) - ext;          // dead prefetch: everything out of range
+        const int mstart = live ? p * B - ext : n;            // dead prefetch (past the team's run): every slot out of range
         const unsigned voff = vo8 + (unsigned)mstart * 8u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) xn[r] = prc_buf_load_c64(rx, voff + 2048u * r, 0u);

@@ -47,8 +47,9 @@ int ls_launch_corr_team(LsFftArgs a, double theta, int teams_per_block, int nblo
                         hipStream_t stream);
 int ls_launch_fir_team(LsFftArgs a, double theta, int nblocks, hipStream_t stream);
 // cached-spectrum chain on the 4096-point transform (ls_fft_team_cached.hip); cache: [block][npieces][4096]
-int64_t ls_team_cache_elems_per_block(int64_t n, int T);
-int ls_team_chain_teams_per_block(int64_t n, int T, int max_blocks);
+int ls_team_piece(int T, int align);            // samples per piece of the chain (align: PRC_OPT_LS_TEAM_ALIGN)
+int64_t ls_team_cache_elems_per_block(int64_t n, int piece);
+int ls_team_chain_teams_per_block(int64_t n, int piece, int max_blocks, int pieces_per_team);
 int ls_launch_corr_cached_team(LsFftArgs a, double theta, int teams_per_block, int nblocks, hipStream_t stream);
 int ls_launch_fused_cached_team(LsFftArgs a, double theta, double theta_out, double gamma_angle, int teams_per_block,
                                 int nblocks, hipStream_t stream);

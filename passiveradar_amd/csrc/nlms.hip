@@ -23,7 +23,6 @@
 // sample).  The step sizes of a window come from the first wavefront's prepass.  The split is for register space only: at
 // T = 1034 a stream alone steps in 253 ns on one wavefront, 334 on two, 302 on four (tools/nlms_waves_probe.py).
 #include "common.h"
-#include <stdlib.h>
 
 struct NlmsArgs {
     const float2* ref;
@@ -298,9 +297,11 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
     PRC_REQUIRE(T <= 8192, PRC_EUNSUPPORTED,
                 "prc_nlms_execute: %d taps exceed the four-wavefront kernel (max 8192)", T);
     int nwave = T <= 2048 ? 1 : (T <= 4096 ? 2 : 4);             // wavefronts per stream
-    // experiment knob (tools/nlms_waves_probe.py): split a config-3 sized filter (T = 1034) over 2 or 4 wavefronts too
-    if (const char* e = getenv("PRC_NLMS_WAVES")) {
-        const int v = atoi(e);
+    // latency experiments (tools/nlms_waves_probe.py): PRC_OPT_NLMS_WAVES = 2 or 4 splits a filter that fits one wavefront
+    // over 2 or 4 as well (honoured for the config-3 filter length, T = 1034, which is what the multi-wavefront
+    // instantiations below cover)
+    {
+        const int v = (int)prc_opt(PRC_OPT_NLMS_WAVES);
         if ((v == 2 || v == 4) && v > nwave && T == 1034) nwave = v;
     }
     const int tpl = ((T + nwave - 1) / nwave + 63) / 64;          // taps per lane: <= 32

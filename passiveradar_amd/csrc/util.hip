@@ -11,18 +11,57 @@ void prc_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-#include <set>
+#include <atomic>
+#include <map>
 #include <utility>
+// hipFuncAttributeMaxDynamicSharedMemorySize is ONE value per (kernel, device): remember the largest request so far and
+// only ever raise it (a later, smaller request must not lower the limit under a launch that still needs the larger one)
 int prc_lds_optin(const void* kernel, int bytes) {
     static std::mutex mtx;
-    static std::set<std::pair<std::pair<const void*, int>, int>> sizes;      // (kernel, device, bytes) already set
+    static std::map<std::pair<const void*, int>, int> largest;
     int dev = 0;
     PRC_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mtx);
-    const auto key = std::make_pair(std::make_pair(kernel, dev), bytes);
-    if (sizes.count(key)) return PRC_OK;
+    const auto key = std::make_pair(kernel, dev);
+    auto it = largest.find(key);
+    if (it != largest.end() && it->second >= bytes) return PRC_OK;
     PRC_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    sizes.insert(key);
+    largest[key] = bytes;
+    return PRC_OK;
+}
+
+// ---- tuning options (prcore.h: prc_option).  Process-wide values; plans copy what concerns them at creation. ----
+static std::atomic<int64_t> g_opt[PRC_OPT_COUNT_];
+static const int64_t g_opt_default[PRC_OPT_COUNT_] = {
+    /* CAF_MULTI_MODE */ PRC_CAF_MULTI_AUTO, /* CAF_GROUP_MB */ 0, /* LS_TEAM_PIECES */ 32, /* LS_TEAM_ALIGN */ 1,
+    /* NLMS_WAVES */ 0, /* LS_CACHE_LIMIT_MB */ 0};
+static std::once_flag g_opt_once;
+static void opt_init() {
+    std::call_once(g_opt_once, [] { for (int i = 0; i < PRC_OPT_COUNT_; ++i) g_opt[i].store(g_opt_default[i]); });
+}
+int64_t prc_opt(int option) {
+    opt_init();
+    return g_opt[option].load();
+}
+extern "C" int prc_set_option(int32_t option, int64_t value) {
+    PRC_REQUIRE(option >= 0 && option < PRC_OPT_COUNT_, PRC_EINVAL, "prc_set_option: unknown option %d", option);
+    opt_init();
+    bool ok = true;
+    switch (option) {
+        case PRC_OPT_CAF_MULTI_MODE: ok = value >= PRC_CAF_MULTI_AUTO && value <= PRC_CAF_MULTI_PAIRS; break;
+        case PRC_OPT_CAF_GROUP_MB: ok = value >= 0; break;
+        case PRC_OPT_LS_TEAM_PIECES: ok = value >= 1 && value <= 4096; break;
+        case PRC_OPT_LS_TEAM_ALIGN: ok = value == 0 || value == 1; break;
+        case PRC_OPT_NLMS_WAVES: ok = value == 0 || value == 1 || value == 2 || value == 4; break;
+        case PRC_OPT_LS_CACHE_LIMIT_MB: ok = value >= 0; break;
+    }
+    PRC_REQUIRE(ok, PRC_EINVAL, "prc_set_option: value %lld out of range for option %d", (long long)value, option);
+    g_opt[option].store(value);
+    return PRC_OK;
+}
+extern "C" int prc_get_option(int32_t option, int64_t* value) {
+    PRC_REQUIRE(value && option >= 0 && option < PRC_OPT_COUNT_, PRC_EINVAL, "prc_get_option: bad argument");
+    *value = prc_opt(option);
     return PRC_OK;
 }
 

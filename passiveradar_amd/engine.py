@@ -32,12 +32,14 @@ class CafPlan:
     """prc_caf_plan: fast_xambg for up to ``max_frames`` frames per launch."""
 
     def __init__(self, n, range_bins, freq_bins, max_frames=1, method=_lib.CAF_AUTO,
-                 doppler=_lib.DOPPLER_AUTO, taps=None):
+                 doppler=_lib.DOPPLER_AUTO, taps=None, multi=_lib.CAF_MULTI_AUTO):
         self.n, self.range_bins, self.freq_bins = int(n), int(range_bins), int(freq_bins)
         self.max_frames = int(max_frames)
         d = _lib.CafDesc()
         d.n, d.range_bins, d.freq_bins = self.n, self.range_bins, self.freq_bins
         d.max_frames, d.method, d.doppler = self.max_frames, int(method), int(doppler)
+        d.multi = _lib.CAF_MULTI_MODES[multi] if isinstance(multi, str) else int(multi)
+        d.reserved = 0
         self._taps = None
         if taps is not None:
             self._taps = np.ascontiguousarray(taps, dtype=np.float32)
@@ -52,6 +54,9 @@ class CafPlan:
         m, dp, ws = C.c_int32(), C.c_int32(), C.c_int64()
         check(lib().prc_caf_plan_info(self._h, C.byref(m), C.byref(dp), C.byref(ws)))
         self.method, self.doppler, self.workspace_bytes = m.value, dp.value, ws.value
+        mm = C.c_int32()
+        check(lib().prc_caf_plan_multi_mode(self._h, C.byref(mm)))
+        self.multi = mm.value               # what AUTO resolved to (turns / shared / pairs)
 
     @property
     def out_shape(self):

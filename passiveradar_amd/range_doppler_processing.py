@@ -43,16 +43,20 @@ def _long_taps(q):
     return np.ascontiguousarray(firwin(10 * q + 1, 1.0 / q, window="flattop"), dtype=np.float32)
 
 
-def caf_plan_for(n, rangeBins, freqBins, shortFilt=True, max_frames=1, method=None, doppler=None, stream=None):
+def caf_plan_for(n, rangeBins, freqBins, shortFilt=True, max_frames=1, method=None, doppler=None, stream=None,
+                 multi=_lib.CAF_MULTI_AUTO):
     method = _DEFAULTS["caf"] if method is None else method
     doppler = _DEFAULTS["doppler"] if doppler is None else doppler
     if not shortFilt and method in (_lib.CAF_FFT, _lib.CAF_FFT4096):
         method = _lib.CAF_AUTO          # the long FIR only exists in the time-domain kernel
     q = int(n / freqBins) if freqBins else 0
-    key = ("caf", n, rangeBins, freqBins, bool(shortFilt), max_frames, method, doppler)
+    multi = _lib.CAF_MULTI_MODES[multi] if isinstance(multi, str) else int(multi)
+    # plans copy the process-wide options when they are made: a cached plan must not outlive a change of them
+    opts = (_lib.get_option(_lib.OPT_CAF_MULTI_MODE), _lib.get_option(_lib.OPT_CAF_GROUP_MB))
+    key = ("caf", n, rangeBins, freqBins, bool(shortFilt), max_frames, method, doppler, multi) + opts
     taps = None if shortFilt else _long_taps(q)
     return engine.cached_plan(key, lambda: engine.CafPlan(n, rangeBins, freqBins, max_frames,
-                                                          method, doppler, taps), stream=stream)
+                                                          method, doppler, taps, multi), stream=stream)
 
 
 def fast_xambg(refChannel, srvChannel, rangeBins, freqBins, inputLen=None, window=None,
@@ -110,11 +114,14 @@ def fast_xambg(refChannel, srvChannel, rangeBins, freqBins, inputLen=None, windo
     return d_out.download((int(freqBins), int(rangeBins) + 1, 1), np.complex64)
 
 
-def fast_xambg_multi(refChannels, srvChannel, rangeBins, freqBins, inputLen=None, window=None, shortFilt=True):
+def fast_xambg_multi(refChannels, srvChannel, rangeBins, freqBins, inputLen=None, window=None, shortFilt=True,
+                     mode="auto"):
     """``[fast_xambg(r, srvChannel, ...) for r in refChannels]`` in one call: several illuminators against ONE
     surveillance channel (BASELINE config 5).  The reference calls fast_xambg once per (reference, surveillance) pair
     (range_doppler_processing.py:12-90); the pairs of one frame share the surveillance channel and the window, so the
-    device transforms the surveillance pieces once per segment for all of them (prc_caf_execute_multi).  Same argument
+    device can transform the surveillance pieces once per segment for all of them (prc_caf_execute_multi; ``mode``:
+    "auto" = the library's measured choice, "turns" = one single-reference pass per illuminator, "shared" / "pairs" =
+    surveillance spectra shared by all / by pairs of illuminators -- prc_caf_desc.multi).  Same argument
     meaning, errors and per-surface result as fast_xambg; returns a list of (freqBins, rangeBins+1, 1) complex64."""
     refs = list(refChannels)
     if not refs:
@@ -123,7 +130,7 @@ def fast_xambg_multi(refChannels, srvChannel, rangeBins, freqBins, inputLen=None
         out = []
         for i in range(0, len(refs), _lib.CAF_MAX_REFS):
             out += fast_xambg_multi(refs[i:i + _lib.CAF_MAX_REFS], srvChannel, rangeBins, freqBins, inputLen, window,
-                                    shortFilt)
+                                    shortFilt, mode)
         return out
     for r in refs:
         if tuple(r.shape) != tuple(srvChannel.shape):                         # :46-49
@@ -144,7 +151,7 @@ def fast_xambg_multi(refChannels, srvChannel, rangeBins, freqBins, inputLen=None
         dev = srvChannel.device
         with torch.cuda.device(dev):
             st = _lib.torch_stream_ptr(dev)
-            plan = caf_plan_for(n, R, F, shortFilt, max_frames=nref, stream=st)
+            plan = caf_plan_for(n, R, F, shortFilt, max_frames=nref, stream=st, multi=mode)
             srv = srvChannel.to(torch.complex64).contiguous()
             rr = [r.to(device=dev, dtype=torch.complex64).contiguous() for r in refs]
             win = None
@@ -154,7 +161,7 @@ def fast_xambg_multi(refChannels, srvChannel, rangeBins, freqBins, inputLen=None
             outs = [torch.empty((F, R + 1, 1), dtype=torch.complex64, device=dev) for _ in refs]
             plan.execute_multi(rr, srv, outs, 1, n, n_in, win, stream=st)
         return outs
-    plan = caf_plan_for(n, R, F, shortFilt, max_frames=nref)
+    plan = caf_plan_for(n, R, F, shortFilt, max_frames=nref, multi=mode)
     st = engine.staging()
     d_srv = st.get("caf_srv", 8 * n_in)
     d_srv.upload(np.ascontiguousarray(srvChannel, dtype=np.complex64))

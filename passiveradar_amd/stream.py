@@ -327,7 +327,7 @@ class HipBackend:
     def __init__(self, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
                  doppler_bins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), clutter="ls",
                  batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, overlap=True,
-                 ls_method=0, nsub=1, ls_streams=3, nref=1, ls_reg=1.0):
+                 ls_method=0, nsub=1, ls_streams=3, nref=1, ls_reg=1.0, caf_multi="auto"):
         """clutter: "ls" = LS_Filter_Multiple over ``doppler_bins`` (main.py:169-176, the reference's choice),
         "ls_direct" = LS_Filter (clutter_removal.py:6-56: circular data matrix, ``ls_reg`` on the Gram diagonal, one
         bin -- SURVEY 8's config-2 "LS_Filter variant"), "nlms" = NLMS_filter with step ``nlms_mu``, None = no canceller."""
@@ -357,7 +357,8 @@ class HipBackend:
         # chunks per LS launch; NLMS is one wavefront per chunk, so splitting a batch would only idle SIMDs
         self.sub = -(-self.batch // max(int(nsub), 1)) if (self.overlap and self.ls_like) else self.batch
         with torch.cuda.device(self.device):
-            self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch * self.nref, caf_method, doppler_method)
+            self.caf = engine.CafPlan(self.cpi, self.R, self.F, self.batch * self.nref, caf_method, doppler_method,
+                                      multi=caf_multi)
             # The LS chain of a sub-batch is a strictly sequential string of kernels, a third of them latency-bound
             # (one Levinson-Durbin per block, per-bin solves: a few wavefronts busy).  Several plans on as many streams
             # run alternate sub-batches concurrently, so one chain's solves sit under the others' HBM-bound passes

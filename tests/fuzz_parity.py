@@ -41,15 +41,12 @@ def worker(wseed):
           ref, srv = scene.make_scene(N, 1e5, min(R, 200), int(rng.integers(1 << 30)))
           w = None if rng.random() < 0.5 else np.kaiser(N, 5.0)
           note("caf_column_doppler", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("cafcol", N, R, F, w is not None))
-      elif k == 21:   # several illuminators against one surveillance channel, both modes of prc_caf_execute_multi
-          import os
+      elif k == 21:   # several illuminators against one surveillance channel, every mode of prc_caf_execute_multi
           nref = int(rng.integers(1, 6)); F = int(rng.choice([2, 8, 16, 256])); N = int(rng.integers(max(8192, 4 * F), 200000))
           R = int(rng.integers(2, min(4000, N // 2 - 1)))
           refs, srv = scene.make_multi_scene(N, 1e5, min(R, 200), [int(rng.integers(1 << 30)) for _ in range(nref)])
           w = None if rng.random() < 0.5 else np.kaiser(N, 5.0)
-          with lock:                                  # the mode is read from the environment at call time
-              os.environ["PRC_CAF_MULTI_MODE"] = str(int(rng.integers(0, 2)))
-              outs = fast_xambg_multi(refs, srv, R, F, N, w)
+          outs = fast_xambg_multi(refs, srv, R, F, N, w, mode=str(rng.choice(["auto", "turns", "shared", "pairs"])))
           i = int(rng.integers(0, nref))
           note("caf_multi", rel(outs[i], O.fast_xambg(refs[i], srv, R, F, N, w)), 2e-5, ("cafmulti", N, R, F, nref, i))
       elif k == 15:   # wide range spans: AUTO takes the 4096-point team kernel (tails, several lag blocks, wrap)

@@ -78,3 +78,52 @@ def test_header_is_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", repo, str(src)])
     if shutil.which("g++"):
         subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", repo, "-x", "c++", str(src)])
+
+
+def test_options_api_without_a_gpu():
+    """prc_set_option / prc_get_option: defaults, round trip, range checks -- no device needed"""
+    from passiveradar_amd import _lib
+    assert _lib.get_option(_lib.OPT_CAF_MULTI_MODE) == _lib.CAF_MULTI_AUTO
+    assert _lib.get_option(_lib.OPT_LS_TEAM_PIECES) == 32 and _lib.get_option(_lib.OPT_LS_TEAM_ALIGN) == 1
+    old = _lib.set_option(_lib.OPT_LS_TEAM_PIECES, 8)
+    try:
+        assert old == 32 and _lib.get_option(_lib.OPT_LS_TEAM_PIECES) == 8
+    finally:
+        _lib.set_option(_lib.OPT_LS_TEAM_PIECES, old)
+    for opt, bad in ((_lib.OPT_CAF_MULTI_MODE, 9), (_lib.OPT_NLMS_WAVES, 3), (_lib.OPT_LS_TEAM_ALIGN, 2), (99, 0)):
+        with pytest.raises(ValueError):
+            _lib.set_option(opt, bad)
+
+
+def test_library_reads_no_environment_variables():
+    """kernel-selection knobs are descriptor fields or prc_set_option: libprcore.so must not even import getenv"""
+    import shutil
+    import subprocess
+    from passiveradar_amd import _lib
+    if shutil.which("nm") is None:
+        pytest.skip("no nm")
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH], text=True)
+    assert not re.search(r"\b(secure_)?getenv\b", undefined)
+    src_dir = os.path.join(REPO, "passiveradar_amd", "csrc")
+    for fn in os.listdir(src_dir):
+        if fn.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(src_dir, fn)).read(), fn
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """sizeof / offsetof of the descriptor structs as gcc lays them out == the ctypes mirrors in _lib.py"""
+    import shutil
+    import subprocess
+    from passiveradar_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "include/prcore.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(prc_caf_desc), offsetof(prc_caf_desc, taps_host), offsetof(prc_caf_desc, multi),\n'
+                   '         sizeof(prc_ls_desc), sizeof(prc_frontend_desc), sizeof(prc_iir_desc)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", REPO, str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
+    want = [ctypes.sizeof(_lib.CafDesc), _lib.CafDesc.taps_host.offset, _lib.CafDesc.multi.offset,
+            ctypes.sizeof(_lib.LsDesc), ctypes.sizeof(_lib.FrontendDesc), ctypes.sizeof(_lib.IirDesc)]
+    assert got == want

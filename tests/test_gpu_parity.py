@@ -759,18 +759,22 @@ def test_auto_picks_the_column_doppler_kernel():
     assert caf_plan_for(5000, 4, 51).doppler == _lib.DOPPLER_ROCFFT
 
 
-def test_batched_frames_in_cache_sized_groups(monkeypatch):
+def test_batched_frames_in_cache_sized_groups():
     """prc_caf_execute alternates segment sums and Doppler transforms over groups of surfaces; a budget of a fraction
     of a surface forces one-frame groups, and the maps must not depend on the grouping"""
     import torch
     from passiveradar_amd import engine
-    n, R, F, nf = 1 << 15, 60, 256, 7
+    n, R, F, nf = 1 << 15, 600, 256, 7               # a surface is 1.2 MB: a 1 MiB budget forces one-frame groups
     ref, srv = scene.make_scene(n // 2 * (nf + 1), 1e5, R, 808)
     a, s = torch.from_numpy(ref).cuda(), torch.from_numpy(srv).cuda()
     outs = []
-    for mb in ("0.01", "0.3", "1000"):
-        monkeypatch.setenv("PRC_CAF_GROUP_MB", mb)
-        plan = engine.CafPlan(n, R, F, nf)
+    from passiveradar_amd import _lib
+    for mb in (1, 0, 3):             # groups of one frame, the whole batch, groups of two frames
+        old = _lib.set_option(_lib.OPT_CAF_GROUP_MB, mb)      # read by the plan at creation
+        try:
+            plan = engine.CafPlan(n, R, F, nf)
+        finally:
+            _lib.set_option(_lib.OPT_CAF_GROUP_MB, old)
         out = torch.zeros((nf, F, R + 1), dtype=torch.complex64, device="cuda")
         plan.execute(a, s, out, nf, n // 2, n, None)
         torch.cuda.synchronize()
@@ -792,19 +796,19 @@ def test_batched_frames_in_cache_sized_groups(monkeypatch):
     (32768, 64, 256, 5, 0, True, None),       # 1024-point method: the fallback of the multi call, column Doppler
     (6000, 6, 64, 2, 0, True, None),          # rocFFT Doppler path
 ])
-@pytest.mark.parametrize("mode", ["turns", "shared"])
-def test_caf_multi_equals_single_calls_and_oracle(n, R, F, nref, caf, win, n_in, mode, monkeypatch):
+@pytest.mark.parametrize("mode", ["turns", "shared", "pairs"])
+def test_caf_multi_equals_single_calls_and_oracle(n, R, F, nref, caf, win, n_in, mode):
     """prc_caf_execute_multi (every reference channel against ONE surveillance channel in one call) returns what one
     fast_xambg per pair returns (range_doppler_processing.py:81-89) -- and what the oracle computes"""
     from passiveradar_amd import range_doppler_processing as rdp
-    # both ways prc_caf_execute_multi can run: one pass per illuminator, or the surveillance transforms shared
-    monkeypatch.setenv("PRC_CAF_MULTI_MODE", {"turns": "0", "shared": "1"}[mode])
+    # every way prc_caf_execute_multi can run (prc_caf_desc.multi): one pass per illuminator, the surveillance
+    # transforms shared by all illuminators, or by pairs of them
     m = n if n_in is None else n_in
     refs, srv = scene.make_multi_scene(m, 1e5, min(R, 200), [7000 + 13 * i + n + R for i in range(nref)])
     w = np.kaiser(n, 5.0) if win else None
     rdp.set_default_methods(caf=caf)
     try:
-        outs = rdp.fast_xambg_multi(refs, srv, R, F, n, w)
+        outs = rdp.fast_xambg_multi(refs, srv, R, F, n, w, mode=mode)
         singles = [rdp.fast_xambg(r, srv, R, F, n, w) for r in refs]
     finally:
         rdp.set_default_methods(caf=0)
@@ -840,18 +844,17 @@ def test_caf_multi_batched_overlapped_frames_and_errors():
     assert rel_err(dd[1].cpu().numpy(), O.fast_xambg(refs[1][:n], srv[:n], R, F)) < TIGHT
 
 
-@pytest.mark.parametrize("mode", ["turns", "shared"])
-def test_caf_cfg5_digest_multi(mode, monkeypatch):
+@pytest.mark.parametrize("mode", ["auto", "turns", "shared", "pairs"])
+def test_caf_cfg5_digest_multi(mode):
     """BASELINE config 5 at full size (N = 2^23, 2048 x 2048, four illuminators against one surveillance channel)
     against digests of the REFERENCE's own fast_xambg, one per illuminator (oracle/gen_golden.py
     caf_cfg5_digest_case); the multi call, which shares the surveillance transforms"""
     from scipy.signal import get_window
     from passiveradar_amd.range_doppler_processing import fast_xambg_multi
-    monkeypatch.setenv("PRC_CAF_MULTI_MODE", {"turns": "0", "shared": "1"}[mode])
     g = load_golden("caf_cfg5_digest")
     n, R, F = int(g["N"]), int(g["R"]), int(g["F"])
     refs, srv = scene.make_multi_scene(n, float(g["fs"]), R, [int(sd) for sd in g["seeds"]])
-    outs = fast_xambg_multi(refs, srv, R, F, n, get_window(("kaiser", 5.0), n))
+    outs = fast_xambg_multi(refs, srv, R, F, n, get_window(("kaiser", 5.0), n), mode=mode)
     for i, out in enumerate(outs):
         out = out[:, :, 0]
         peak = float(g[f"ill{i}_peak"])

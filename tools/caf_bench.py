@@ -26,14 +26,15 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--caf-method", type=int, default=0)
     ap.add_argument("--doppler", type=int, default=0)
-    ap.add_argument("--group-mb", type=float, default=None)
+    ap.add_argument("--group-mb", type=int, default=None)
+    ap.add_argument("--multi", default="auto", choices=["auto", "turns", "shared", "pairs"])
     ap.add_argument("--tag", default="")
     args = ap.parse_args()
-    if args.group_mb is not None:
-        os.environ["PRC_CAF_GROUP_MB"] = str(args.group_mb)
     import torch
     from passiveradar_amd import _lib, engine
     _lib.require_gpu()
+    if args.group_mb is not None:
+        _lib.set_option(_lib.OPT_CAF_GROUP_MB, int(args.group_mb))
     n, R, F = SHAPES[args.shape]
     C = n // 2
     nf, nref = args.frames, args.nref
@@ -45,7 +46,7 @@ def main():
     refs = [mk() for _ in range(nref)]
     srv = mk()
     win = torch.from_numpy(np.kaiser(n, 5.0).astype(np.float32)).to(dev)
-    plan = engine.CafPlan(n, R, F, nf * nref, args.caf_method, args.doppler)
+    plan = engine.CafPlan(n, R, F, nf * nref, args.caf_method, args.doppler, multi=args.multi)
     outs = [torch.empty((nf, F, R + 1), dtype=torch.complex64, device=dev) for _ in range(nref)]
     s = _lib.torch_stream_ptr()
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -64,7 +65,7 @@ def main():
         return float(np.median(ts))
 
     res = {"lib": os.environ.get("PRCORE_LIB", "default"), "tag": args.tag, "shape": args.shape, "frames": nf,
-           "nref": nref, "method": plan.method, "doppler": plan.doppler}
+           "nref": nref, "method": plan.method, "doppler": plan.doppler, "multi": plan.multi}
     res["segments_ms"] = timeit(lambda: plan.execute_segments(refs[0], srv, nf, C, n, win, s))
     res["doppler_ms"] = timeit(lambda: plan.execute_doppler(outs[0], nf, s))
     res["execute_ms"] = timeit(lambda: plan.execute(refs[0], srv, outs[0], nf, C, n, win, s))

@@ -1,7 +1,7 @@
 """Does splitting one NLMS stream over several wavefronts buy latency?  T = 1034 (config 3) on one, two and four wavefronts
-per stream (PRC_NLMS_WAVES, honoured for this filter length only): ns per step of a single stream, and the throughput of
+per stream (prc_set_option(PRC_OPT_NLMS_WAVES), honoured for this filter length only): ns per step of a single stream, and the throughput of
 3072 concurrent streams.      python tools/nlms_waves_probe.py"""
-import os, sys, time, torch
+import sys, time, torch
 sys.path.insert(0, ".")
 from passiveradar_amd import engine, _lib
 dev = torch.device("cuda")
@@ -13,7 +13,7 @@ for ns, n in ((1, 200000), (3072, 30000)):
     srv = torch.roll(ref, 2) + 0.01 * torch.view_as_complex(torch.randn((ns * n, 2), generator=g, device=dev))
     outs = {}
     for waves in (1, 2, 4):
-        os.environ["PRC_NLMS_WAVES"] = str(waves)
+        _lib.set_option(_lib.OPT_NLMS_WAVES, waves)
         out = torch.empty_like(srv)
         engine.nlms_execute(ref, srv, out, n, L, 0.02, 10, None, None, ns, n, n, s); torch.cuda.synchronize()
         t = time.perf_counter()
