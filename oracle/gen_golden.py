@@ -453,6 +453,77 @@ def pipeline_cfg2_c128_case():
          cleaned_sub=cleaned[::101].astype(np.complex64), out=out[:, :, 0].astype(np.complex64))
 
 
+def pipeline_prconfig_raw_case():
+    """The reference's published workload, end to end, as shipped (PRconfig.yaml unmodified: 2 s CPI, 1024 Doppler x 176
+    range cells, LS x 5 bins, T = 185): three raw int8 blocks of 4 799 250 scalars per channel through the reference's own
+    deinterleave_IQ -> frequency_shift(block phase) -> resample(13, 119) -> LS_Filter_Multiple -> fast_xambg in the
+    geometry of main.py:105-194 (50 % overlapped CPIs, zero boundary, Kaiser(5) window); the middle frame, a digest of
+    the IF streams and of the cleaned stream."""
+    print("PRconfig.yaml raw -> frame (front end + LS x5 + CAF at the shipped sizes)")
+    cfg = ref_cfg.getConfiguration("/root/reference/PRconfig.yaml")
+    icl, fs_in, foff = cfg["input_chunk_length"], cfg["input_sample_rate"], cfg["offset_freq"]
+    up, dn, C, n = cfg["resamp_up"], cfg["resamp_dn"], cfg["output_chunk_length"], cfg["cpi_samples"]
+    R, F, fs_if = cfg["num_range_cells"], cfg["num_doppler_cells"], cfg["IF_sample_rate"]
+    nblk = 3
+    seed = scene.scene_seed(14)
+    raw_ref, raw_srv = scene.make_raw_stream(nblk, icl, fs_in, foff, seed)
+    t0 = time.time()
+    mod_period = fs_in // foff
+    per_block = (icl // 2) % mod_period
+    phases = 2 * np.pi * np.arange(nblk) * per_block * (foff / fs_in)          # main.py:125-131
+
+    def front(raw):
+        out = []
+        for i in range(nblk):
+            blk = ref_su.deinterleave_IQ(raw[i * icl:(i + 1) * icl])
+            tuned = ref_su.frequency_shift(blk, foff, fs_in, np.array([phases[i]]))
+            out.append(ref_su.resample(tuned, up, dn))
+        return np.concatenate(out)
+    a, s = front(raw_ref), front(raw_srv)
+    assert a.shape[0] == nblk * C, (a.shape, C)
+    print(f"  front end {time.time() - t0:.1f}s")
+    # main.py:169-176 declares dtype=complex64 for these arrays; the functions receive what resample returned (complex128)
+    t0 = time.time()
+    cleaned = np.concatenate([
+        ref_cr.LS_Filter_Multiple(a[i * C:(i + 1) * C], s[i * C:(i + 1) * C], R, fs_if, [0, 1, -1, 2, -2])
+        for i in range(nblk)])
+    print(f"  LS_Filter_Multiple x{nblk} {time.time() - t0:.1f}s")
+    depth = cfg["window_overlap"]
+    pad = np.zeros(depth)
+    ap = np.concatenate((pad, a, pad))
+    sp = np.concatenate((pad, cleaned, pad))
+    w = signal.get_window(("kaiser", 5.0), n)
+    t0 = time.time()
+    with no_root_finding():
+        out = ref_rd.fast_xambg(ap[C:C + n], sp[C:C + n], R, F, n, w)
+    print(f"  fast_xambg {time.time() - t0:.1f}s")
+    keys = ("input_chunk_length", "input_sample_rate", "offset_freq", "resamp_up", "resamp_dn", "output_chunk_length",
+            "cpi_samples", "num_range_cells", "num_doppler_cells", "IF_sample_rate", "window_overlap")
+    save("pipeline_prconfig_raw", seed=seed, nblk=nblk, frame_index=1,
+         **{"cfg_" + k: cfg[k] for k in keys},
+         raw_ref_checksum=np.array(scene.raw_checksum(raw_ref), dtype=np.int64),
+         raw_srv_checksum=np.array(scene.raw_checksum(raw_srv), dtype=np.int64),
+         if_ref_sub=a[::61].astype(np.complex64), if_srv_sub=s[::61].astype(np.complex64),
+         if_ref_rms=float(np.sqrt(np.mean(np.abs(a) ** 2))), if_srv_rms=float(np.sqrt(np.mean(np.abs(s) ** 2))),
+         cleaned_sub=cleaned[::61].astype(np.complex64), cleaned_rms=float(np.sqrt(np.mean(np.abs(cleaned) ** 2))),
+         out=out[:, :, 0].astype(np.complex64))
+
+
+def caf_longfilt_cfg1_case():
+    """fast_xambg(..., shortFilt=False) at a BASELINE size (config 1: N = 262 144, 257 lags, 256 Doppler bins): the
+    decimation filter is firwin(10 q + 1, 1/q, 'flattop') with q = 1024, 10 241 taps per output sample
+    (range_doppler_processing.py:73-78)."""
+    print("config-1 CAF with the long decimation FIR (shortFilt=False)")
+    n, R, F, fs = 262144, 256, 256, 262184.87
+    a, s = scene.make_scene(n, fs, R, scene.scene_seed(1))
+    w = signal.get_window(("kaiser", 5.0), n)
+    t0 = time.time()
+    with no_root_finding():
+        out = ref_rd.fast_xambg(a, s, R, F, n, w, shortFilt=False)
+    print(f"  {time.time() - t0:.1f}s")
+    save("caf_longfilt_cfg1", seed=scene.scene_seed(1), N=n, R=R, F=F, fs=fs, out=out[:, :, 0].astype(np.complex64))
+
+
 def ls_wide_cases():
     """LS_Filter_Multiple with Doppler bins far from zero (|2 pi f/Fs| * peek up to ~0.4 rad: the reference accepts
     any bin list, clutter_removal.py:178-187) and the LS filters at the config-3 tap count T = 1034."""
@@ -510,3 +581,5 @@ if __name__ == "__main__":
         pipeline_cfg2_c128_case()
         nlms_cfg3_digest_case()
         caf_cfg5_digest_case()
+        pipeline_prconfig_raw_case()
+        caf_longfilt_cfg1_case()

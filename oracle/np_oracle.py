@@ -371,7 +371,7 @@ def overlap_frames(stream, chunk, depth):
 
 
 def process_stream(ref, srv, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
-                   dopplerBins=(0, 1, -1, 2, -2), window=("kaiser", 5.0)):
+                   dopplerBins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), return_cleaned=False):
     """main.py:169-194 on an in-memory IF stream: per-chunk LS_Filter_Multiple (chunk =
     cpi/2, :169-176), zero-boundary overlap of depth cpi/4 (:178-181), Kaiser window (:183),
     fast_xambg per frame (:186-194), frames stacked on axis 2."""
@@ -387,7 +387,8 @@ def process_stream(ref, srv, cpi_samples, num_range_cells, num_doppler_cells, IF
     sf = overlap_frames(cleaned, C, depth)
     frames = [fast_xambg(a, b, num_range_cells, num_doppler_cells, cpi_samples, w)
               for a, b in zip(rf, sf)]
-    return np.concatenate(frames, axis=2)
+    out = np.concatenate(frames, axis=2)
+    return (out, cleaned) if return_cleaned else out
 
 
 # --------------------------------------------------------------------------

@@ -72,6 +72,12 @@ struct CafFftArgs {
 template <bool HAS_WIN, int NLB>
 __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_kernel(CafFftArgs a) {
     constexpr bool PREFETCH = NLB != 1;
+    // single-lag-block form: the surveillance loads of a piece are issued BEFORE the reference transform and fly under it
+#ifdef CAFF_LATE_V
+    constexpr bool EARLY_V = false;
+#else
+    constexpr bool EARLY_V = NLB == 1;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
     float2* tile = tab + FFTW_TABLE + (threadIdx.x >> 6) * FFTW_TILE;
@@ -119,6 +125,11 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
         float wn[16];
         // nz: registers r >= nz lie beyond the piece for every lane (64 r >= cnt): not loaded, zero
         auto issue_u = [&](int n0, int nz = 16) {
+#ifdef CAFF_EXP_NOLOAD      // timing ablation only (wrong results): no global loads
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { un[r] = make_float2((float)(lane + n0), (float)r); wn[r] = 0.5f; }
+            return;
+#endif
             const int rem = hi - n0 + 1;
             int cnt = rem < B ? rem : B;
             if (NV - n0 < cnt) cnt = NV - n0;
@@ -139,6 +150,11 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
         };
         // srv slots [0, cnt+LB-1) of lag block lb: frame offsets start .. with circular wrap (:82)
         auto issue_v = [&](float2 (&v)[16], int n0, int cnt, int lb) {
+#ifdef CAFF_EXP_NOLOAD
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = make_float2((float)(lane - n0), (float)(r + cnt + lb));
+            return;
+#endif
             int start = n0 + lb * LB;
             if (start >= N) start -= N;
             const int want = cnt + LB - 1;
@@ -174,6 +190,7 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     u[r] = r < 8 ? (HAS_WIN ? cscale(un[r], wn[r]) : un[r]) : make_float2(0.f, 0.f);
+                if (EARLY_V) issue_v(v[0], n0, cnt, lb0);
                 __builtin_amdgcn_sched_barrier(0);
                 fft1024_fwd<8>(u, tile, tab, f);
             } else if (nz == 12) {
@@ -181,6 +198,7 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     u[r] = r < 12 ? (HAS_WIN ? cscale(un[r], wn[r]) : un[r]) : make_float2(0.f, 0.f);
+                if (EARLY_V) issue_v(v[0], n0, cnt, lb0);
                 __builtin_amdgcn_sched_barrier(0);
                 fft1024_fwd<12>(u, tile, tab, f);
             } else {
@@ -188,16 +206,16 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     u[r] = HAS_WIN ? cscale(un[r], wn[r]) : un[r];
-                if (PREFETCH) issue_v(v[0], n0, cnt, lb0);
+                if (PREFETCH || EARLY_V) issue_v(v[0], n0, cnt, lb0);
                 __builtin_amdgcn_sched_barrier(0);
                 fft1024_fwd(u, tile, tab, f);
             }
 #pragma unroll
             for (int l = 0; l < NLB; ++l) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (!PREFETCH)
-                    issue_v(v[l], n0, cnt, lb0 + l);
-                else if (l + 1 < NLB)
+                if (!PREFETCH) {
+                    if (!EARLY_V) issue_v(v[l], n0, cnt, lb0 + l);
+                } else if (l + 1 < NLB)
                     issue_v(v[l + 1 < NLB ? l + 1 : 0], n0, cnt, lb0 + l + 1);
                 else
                     issue_u(n0 + B);                        // past the last piece: zero records -> zeros

@@ -108,6 +108,9 @@ __device__ __forceinline__ FtLane ft_setup(float2* lds, const float2* __restrict
     return f;
 }
 
+#ifdef FT_EXP_NOBARRIER          // timing ablation only (wrong results)
+#define FT_BARRIER() ((void)0)
+#endif
 #ifndef FT_BARRIER
 #define FT_BARRIER() __syncthreads()
 #endif

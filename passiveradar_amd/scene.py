@@ -114,3 +114,48 @@ def make_fm_scene(n, sample_rate, rangeBins, seed, deviation=75e3, audio_bw=15e3
         acc += a * np.roll(ref, d) * np.exp(2j * np.pi * fd * t)
     acc += kw.get("noise_amp", 0.003) * noise
     return ref, acc.astype(np.complex64)
+
+
+def make_raw_stream(nchunks, input_chunk_length, input_sample_rate, offset_freq, seed, channel_bw=200e3,
+                    clutter=((18, 1.0), (83, 0.3), (366, 0.1)),
+                    targets=((549, 80.0, 0.03), (1190, -35.0, 0.01)), sigma=24.0, noise_amp=0.01):
+    """Raw two-channel recordings as main.py:44-112 reads them: interleaved int8 I,Q scalars at ``input_sample_rate``,
+    ``input_chunk_length`` scalars per block and channel.  The illuminator is Gaussian noise band-limited to
+    ``channel_bw`` sitting ``offset_freq`` BELOW the recording's centre (PRconfig.yaml: channel 101.9 MHz in a recording
+    centred on 102.0 MHz), so that the reference's frequency_shift(+offset_freq) brings it to baseband; the surveillance
+    channel is delayed copies (delays in raw samples: 9.15 per IF sample at 13/119), two moving echoes and receiver
+    noise.  Both channels are quantised to int8 independently.  Returns (raw_ref, raw_srv), int8 [nchunks * icl]."""
+    from math import pi
+    n = nchunks * (int(input_chunk_length) // 2)
+    gen = np.random.Generator(np.random.Philox(key=seed))
+    white = gen.standard_normal(2 * n).view(np.complex128) * np.sqrt(0.5)
+    # windowed-sinc low-pass to the channel bandwidth (two-sided), 65 taps
+    m = np.arange(-32, 33)
+    fcut = 0.5 * channel_bw / float(input_sample_rate)
+    h = 2 * fcut * np.sinc(2 * fcut * m) * np.hamming(65)
+    base = np.convolve(white, h, mode="same")
+    base /= np.sqrt(np.mean(np.abs(base) ** 2))
+    t = np.arange(n, dtype=np.float64) / float(input_sample_rate)
+    down = np.exp(-2j * pi * float(offset_freq) * t)
+    noise_r = gen.standard_normal(2 * n).view(np.complex128) * np.sqrt(0.5)
+    noise_s = gen.standard_normal(2 * n).view(np.complex128) * np.sqrt(0.5)
+    acc = np.zeros(n, dtype=np.complex128)
+    for d, a in clutter:
+        acc += a * np.roll(base, d)
+    for d, fd, a in targets:
+        acc += a * np.roll(base, d) * np.exp(2j * pi * fd * t)
+
+    def quantise(x):
+        iq = np.empty(2 * n, dtype=np.float64)
+        iq[0::2], iq[1::2] = x.real, x.imag
+        return np.clip(np.rint(iq * sigma), -127, 127).astype(np.int8)
+    raw_ref = quantise((base + noise_amp * noise_r) * down)
+    raw_srv = quantise((acc + noise_amp * noise_s) * down)
+    return raw_ref, raw_srv
+
+
+def raw_checksum(raw):
+    """(sum, sum of squares, CRC32) of an int8 recording: a regenerated stream is checked against its golden's"""
+    import zlib
+    a = np.asarray(raw).astype(np.int64)
+    return int(a.sum()), int((a * a).sum()), int(zlib.crc32(np.ascontiguousarray(raw).tobytes()))

@@ -105,6 +105,14 @@ class FrameComm:
         _lib.check(_lib.lib().prc_gather_frames(self._h, _ptr(send), cnt, int(frame_elems), _ptr(recv), int(root),
                                                 stream))
 
+    def count(self):
+        """(ranks, this rank) as RCCL reports them for the communicator it built (prc_comm_count)"""
+        import ctypes as C
+        from . import _lib
+        n, r = C.c_int32(0), C.c_int32(0)
+        _lib.check(_lib.lib().prc_comm_count(self._h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
+
     def close(self):
         if getattr(self, "_h", None):
             from . import _lib
@@ -116,6 +124,13 @@ class FrameComm:
             self.close()
         except Exception:
             pass
+
+
+class _NoWork:
+    """work handle of a gather that had nothing to move (a world of one, an empty round)"""
+
+    def wait(self):
+        return None
 
 
 class _StreamWork:
@@ -156,12 +171,19 @@ def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, com
     before reusing ``local``)."""
     import torch
     if shard.world == 1:
-        return (local, None) if async_op else local
+        if out is not None and out.data_ptr() != local.data_ptr():
+            out.copy_(local)
+            local = out
+        return (local, _NoWork()) if async_op else local
     F, cols = local.shape[1], local.shape[2]
     counts = shard_sizes(shard) if counts is None else [int(c) for c in counts]
     if len(counts) != shard.world:
         raise ValueError(f"gather_frames: {len(counts)} counts for a world of {shard.world}")
     total = sum(counts)
+    if total == 0:
+        # a round in which no rank has frames (more rounds than frames): nothing to move, no collective, no buffers
+        empty = torch.empty((0, F, cols), dtype=torch.complex64, device=local.device)
+        return (empty, _NoWork()) if async_op else empty
     if comm is not None:
         # the C-ABI path knows nothing of torch.distributed: ranks, the root and the world are the communicator's own
         # (a FrameComm built over a sub-group, or over any other side channel, numbers its ranks from 0)
@@ -297,7 +319,8 @@ class _PlacedWork:
             self.ev.record(st)
 
     def wait(self):
-        self.work.wait()
+        if self.work is not None:
+            self.work.wait()
         if not self.done:
             self.place()
             self.done = True

@@ -198,3 +198,50 @@ def test_part_gather_assembles_the_frame_ordered_array(world):
         p.join(timeout=240)
         assert p.exitcode == 0
     assert ok
+
+
+def _failing_worker(rank, world, port, q):
+    """rank 1 throws before the collective the other ranks are already waiting in"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from mp_util import report_failure_and_leave, report_ok
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if rank == 1:
+            raise RuntimeError("rank 1 fails before the barrier")
+        dist.barrier()                          # never completes: rank 1 is gone
+        report_ok(q, rank)
+    except Exception as e:                      # noqa: BLE001
+        report_failure_and_leave(q, rank, e)
+
+
+def test_a_failing_rank_ends_the_run_at_once():
+    """the multi-rank GPU test (tests/test_gpu_gather_rccl.py) runs through mp_util.run_ranks: a rank that throws must
+    fail the test within seconds, with its traceback, and leave no process behind -- not block the healthy ranks in a
+    collective until a 600 s timeout"""
+    import time
+    from mp_util import run_ranks
+    t0 = time.time()
+    ok, got, codes = run_ranks(mp.get_context("spawn"), _failing_worker, 3, args=(_free_port(),), deadline_s=120)
+    took = time.time() - t0
+    assert not ok and took < 60, (took, got, codes)
+    assert any(r == 1 and "rank 1 fails before the barrier" in msg for r, msg in got), got
+    assert all(c is not None for c in codes), codes          # every process is gone (killed or exited)
+
+
+def test_part_gather_edge_cases_single_rank():
+    """a world of one with async_op (no work handle to wait for) and a round in which nobody has frames"""
+    from passiveradar_amd.stream import PartGather, Shard, gather_frames
+    sh = Shard(0, 1, 3, 0, 3, 0, 3)
+    mine = torch.arange(3 * 4, dtype=torch.float32).reshape(3, 2, 2).to(torch.complex64)
+    res, work = gather_frames(mine, sh, async_op=True)
+    work.wait()                                  # must not raise although nothing was communicated
+    assert torch.equal(res, mine)
+    pg = PartGather(sh, 5)                       # more rounds than frames: two of them are empty
+    result = torch.zeros_like(mine)
+    works = [pg.gather_part(p, mine[slice(*pg.part_range(p))], result, async_op=True) for p in range(5)]
+    for w in works:
+        w.wait()
+    assert torch.equal(result, mine)

@@ -10,6 +10,8 @@ import socket
 import numpy as np
 import pytest
 
+from mp_util import report_failure_and_leave, report_ok, run_ranks
+
 pytestmark = pytest.mark.gpu
 
 
@@ -32,6 +34,8 @@ def _worker(rank, world, port, q):
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
         comm = FrameComm.from_torch_distributed()
+        # what RCCL itself says about the communicator (prc_comm_count): the number of ranks it connected, this rank's id
+        assert comm.count() == (world, rank), comm.count()
         F, cols = 8, 5
         # ragged blocks (ceil split of 2 * world + 1 frames), root 0 and root world - 1
         total = 2 * world + 1
@@ -71,12 +75,13 @@ def _worker(rank, world, port, q):
             err = float((full - one).abs().max() / one.abs().max())
             assert err < 1e-6, err
         comm.close()
-        q.put((rank, "ok"))
-    except Exception as e:                      # noqa: BLE001 -- reported to the parent, which fails the test
-        q.put((rank, repr(e)))
-    finally:
+        report_ok(q, rank)
+        # a clean exit only: every rank got here, so this barrier cannot wait for a rank that threw (a failing rank
+        # reports and leaves at once below; the parent then ends the others instead of letting them sit in a collective)
         dist.barrier()
         dist.destroy_process_group()
+    except Exception as e:                      # noqa: BLE001 -- reported to the parent, which fails the test
+        report_failure_and_leave(q, rank, e)    # no collective on the way out: the other ranks may be inside one
 
 
 def test_prc_gather_frames_between_ranks(gpu_ready):
@@ -86,13 +91,5 @@ def test_prc_gather_frames_between_ranks(gpu_ready):
     if world < 2:
         pytest.skip("needs at least two GPUs: the multi-rank RCCL branch of prc_gather_frames")
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=600) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=600)
-    assert all(msg == "ok" for _, msg in got), got
-    assert all(p.exitcode == 0 for p in procs)
+    ok, got, codes = run_ranks(ctx, _worker, world, args=(_free_port(),), deadline_s=420)
+    assert ok, (got, codes)

@@ -400,3 +400,37 @@ def test_bench_cfg5_maps_against_single_calls(tmp_path):
     for i in range(4):
         one = fast_xambg(refs[i][:n], srv_pad[:n], R, F, n, win)[:, :, 0].cpu().numpy()
         assert rel_err(d[f"ill{i}_frames"][0], one) < 1e-6, i
+
+
+def test_prconfig_raw_to_frame_against_reference_output():
+    """The reference's published workload end to end at the shipped sizes (PRconfig.yaml unmodified): three raw int8
+    blocks of 4 799 250 scalars per channel -> device front end (deinterleave, tune with block phases, 13:119) ->
+    LS_Filter_Multiple x 5 bins (T = 185) on 262 144-sample chunks -> the middle overlapped 1024 x 176 frame
+    (main.py:105-194), against what the reference's own functions produced (golden pipeline_prconfig_raw, made by
+    oracle/gen_golden.py pipeline_prconfig_raw_case): IF streams, cleaned stream and the map, each within 1e-4."""
+    import torch
+    from passiveradar_amd import scene
+    from passiveradar_amd.stream import HipBackend, StreamProcessor
+    g = load_golden("pipeline_prconfig_raw")
+    cfg = {k[4:]: (float(g[k]) if k == "cfg_IF_sample_rate" else int(g[k])) for k in g.files if k.startswith("cfg_")}
+    raw_ref, raw_srv = scene.make_raw_stream(int(g["nblk"]), cfg["input_chunk_length"], cfg["input_sample_rate"],
+                                             cfg["offset_freq"], int(g["seed"]))
+    if (list(scene.raw_checksum(raw_ref)) != [int(v) for v in g["raw_ref_checksum"]] or
+            list(scene.raw_checksum(raw_srv)) != [int(v) for v in g["raw_srv_checksum"]]):
+        pytest.skip("the regenerated raw stream differs from the golden's (another libm / NumPy build)")
+    be = HipBackend(cfg["cpi_samples"], cfg["num_range_cells"], cfg["num_doppler_cells"], cfg["IF_sample_rate"], batch=3)
+    args = (cfg["input_chunk_length"], cfg["offset_freq"], cfg["input_sample_rate"], cfg["resamp_up"], cfg["resamp_dn"])
+    a, s = be.front_end(raw_ref, *args), be.front_end(raw_srv, *args)
+    assert a.shape[0] == int(g["nblk"]) * cfg["output_chunk_length"]
+    assert rel_err(a[::61].cpu().numpy(), g["if_ref_sub"]) < 1e-4 and rel_err(s[::61].cpu().numpy(), g["if_srv_sub"]) < 1e-4
+    sp = StreamProcessor(be)
+    frames = sp.process_raw(raw_ref, raw_srv, cfg)
+    torch.cuda.synchronize()
+    X = frames[int(g["frame_index"])].cpu().numpy()
+    assert X.shape == g["out"].shape and rel_err(X, g["out"]) < 1e-4
+    # the cleaned stream the frames were made of (clutter 40 dB down: normalised by the level of what went in)
+    ref_pad, srv_pad = be.padded(a), be.padded(s)
+    clean = be.clean(ref_pad, srv_pad, int(g["nblk"]))
+    C = cfg["output_chunk_length"]
+    got = clean[C // 2:C // 2 + int(g["nblk"]) * C][::61].cpu().numpy()
+    assert np.abs(got - g["cleaned_sub"]).max() / float(g["if_srv_rms"]) < 1e-4

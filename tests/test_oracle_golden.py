@@ -306,3 +306,31 @@ def test_nlms_cfg3_hop_c_twin_vs_reference_digest():
     assert np.abs(out[-4096:] - g["tail"]).max() / peak < 1e-4
     assert rel_err(taps, g["taps"]) < 1e-4
     assert abs(float(np.vdot(out, out).real) / float(g["energy"]) - 1) < 1e-4
+
+
+def _prconfig_raw(g):
+    """the golden's raw int8 recordings, regenerated from its seed and checked against its checksums"""
+    icl, fs_in, foff = int(g["cfg_input_chunk_length"]), int(g["cfg_input_sample_rate"]), int(g["cfg_offset_freq"])
+    raw_ref, raw_srv = scene.make_raw_stream(int(g["nblk"]), icl, fs_in, foff, int(g["seed"]))
+    if (list(scene.raw_checksum(raw_ref)) != [int(v) for v in g["raw_ref_checksum"]] or
+            list(scene.raw_checksum(raw_srv)) != [int(v) for v in g["raw_srv_checksum"]]):
+        pytest.skip("the regenerated raw stream differs from the golden's (another libm / NumPy build)")
+    return raw_ref, raw_srv
+
+
+def test_prconfig_raw_to_frame_restatement():
+    """The reference's published workload as shipped (PRconfig.yaml: raw int8 -> tune -> 13:119 -> LS x5, T = 185 ->
+    1024 x 176 CAF, main.py:105-194): the oracle's restatement against the reference's own IF streams, cleaned stream
+    and middle frame, at full size"""
+    g = load_golden("pipeline_prconfig_raw")
+    raw_ref, raw_srv = _prconfig_raw(g)
+    icl, fs_in, foff = int(g["cfg_input_chunk_length"]), int(g["cfg_input_sample_rate"]), int(g["cfg_offset_freq"])
+    up, dn, n = int(g["cfg_resamp_up"]), int(g["cfg_resamp_dn"]), int(g["cfg_cpi_samples"])
+    R, F, fs = int(g["cfg_num_range_cells"]), int(g["cfg_num_doppler_cells"]), float(g["cfg_IF_sample_rate"])
+    a = O.front_end(raw_ref, icl, foff, fs_in, up, dn)
+    s = O.front_end(raw_srv, icl, foff, fs_in, up, dn)
+    assert a.shape[0] == int(g["nblk"]) * int(g["cfg_output_chunk_length"])
+    assert rel_err(a[::61], g["if_ref_sub"]) < 1e-5 and rel_err(s[::61], g["if_srv_sub"]) < 1e-5
+    frames, cleaned = O.process_stream(a, s, n, R, F, fs, return_cleaned=True)
+    assert np.abs(cleaned[::61] - g["cleaned_sub"]).max() / float(g["if_srv_rms"]) < 1e-4
+    assert rel_err(frames[:, :, int(g["frame_index"])], g["out"]) < 1e-4
