@@ -97,10 +97,16 @@ def caf_segment_sums(ref, srv, rangeBins, freqBins, window=None, taps=None):
             b = np.clip(hi + 1, 0, N)
             y[:, k] = cs[b] - cs[a]
         else:
-            full = np.convolve(prod, h)                    # full[t] = sum_m h[m] prod[t-m]
+            # full = np.convolve(prod, h), full[t] = sum_m h[m] prod[t-m], taken only at the F outputs t_j = j q + half
+            # (resample_poly keeps those): rows of a strided view of the zero-padded products against the reversed taps
+            nt = h.size
+            P = np.concatenate((np.zeros(nt - 1, dtype=np.complex128), prod, np.zeros(nt, dtype=np.complex128)))
             idx = centres + half
-            ok = idx < full.size
-            y[ok, k] = full[idx[ok]]
+            ok = idx < N + nt - 1
+            W = np.lib.stride_tricks.as_strided(P[half:], shape=(freqBins, nt),
+                                                strides=(q * P.itemsize, P.itemsize), writeable=False)
+            yk = W @ h[::-1]
+            y[ok, k] = yk[ok]
     return y
 
 

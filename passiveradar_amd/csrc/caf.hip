@@ -25,6 +25,7 @@ struct prc_caf_plan {
     int ntaps;
     int half;
     float* d_taps = nullptr;         // device copy of the long decimation FIR (or null)
+    float* d_taps_rev = nullptr;     // ... and in reverse order (the FFT segment kernel's weight stream)
     float2* d_y = nullptr;           // [k][j]-ordered slow-time buffer of the rocFFT path, max_frames * F * (R+1)
     float2* d_y2 = nullptr;          // [j][k]-ordered slow-time buffer written row-wise by the segment kernels
     float2* d_dop_tw = nullptr;      // W_F^m table of the column-FFT Doppler kernel
@@ -149,7 +150,19 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
     PRC_REQUIRE(d->multi >= PRC_CAF_MULTI_AUTO && d->multi <= PRC_CAF_MULTI_PAIRS, PRC_EINVAL,
                 "prc_caf_plan_create: unknown multi mode %d", d->multi);
     p->multi = d->multi != PRC_CAF_MULTI_AUTO ? d->multi : (int)prc_opt(PRC_OPT_CAF_MULTI_MODE);
-    if (p->multi == PRC_CAF_MULTI_AUTO) p->multi = PRC_CAF_MULTI_DEFAULT;
+    if (p->multi == PRC_CAF_MULTI_AUTO) {
+        // measured on MI355X, four illuminators (tools/caf_bench.py --nref 4): config-3 span (1025
+        // lags, pieces of 3072 + a remainder) shared 110 us per frame against 120 for turns; config-5 span (2049 lags, two
+        // pieces of 2048) shared 324-329 against 313 -- sharing pays where a segment's first piece is longer than 2048
+        // samples (fewer, longer transforms per illuminator next to the two shared ones)
+        p->multi = PRC_CAF_MULTI_TURNS;
+        if (p->method == PRC_CAF_FFT4096 && p->doppler == PRC_DOPPLER_COLUMN &&
+            caf_team_multi_supported(d->n, d->range_bins, d->freq_bins, p->ntaps, 2)) {
+            int nlb = 1, lb = d->range_bins + 1;
+            caf_team_multi_blocking(p->ntaps, d->range_bins, 2, &nlb, &lb);
+            if (4097 - lb > 2048) p->multi = PRC_CAF_MULTI_SHARED;
+        }
+    }
     if (p->doppler != PRC_DOPPLER_ROCFFT && p->doppler != PRC_DOPPLER_COLUMN) {
         prc_set_error("prc_caf_plan_create: unknown Doppler method %d", d->doppler);
         delete p;
@@ -170,8 +183,12 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
         return fail(PRC_EHIP);
     }
     if (!boxcar) {
+        std::vector<float> rev((size_t)d->ntaps);
+        for (int i = 0; i < d->ntaps; ++i) rev[i] = d->taps_host[d->ntaps - 1 - i];
         if (hipMalloc(&p->d_taps, sizeof(float) * d->ntaps) != hipSuccess ||
-            hipMemcpy(p->d_taps, d->taps_host, sizeof(float) * d->ntaps, hipMemcpyHostToDevice) != hipSuccess) {
+            hipMemcpy(p->d_taps, d->taps_host, sizeof(float) * d->ntaps, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMalloc(&p->d_taps_rev, sizeof(float) * d->ntaps) != hipSuccess ||
+            hipMemcpy(p->d_taps_rev, rev.data(), sizeof(float) * d->ntaps, hipMemcpyHostToDevice) != hipSuccess) {
             prc_set_error("prc_caf_plan_create: taps upload failed");
             return fail(PRC_EHIP);
         }
@@ -198,6 +215,7 @@ extern "C" int prc_caf_plan_destroy(prc_caf_plan* p) {
     if (p->fft) rocfft_plan_destroy(p->fft);
     if (p->d_work) (void)hipFree(p->d_work);
     if (p->d_taps) (void)hipFree(p->d_taps);
+    if (p->d_taps_rev) (void)hipFree(p->d_taps_rev);
     if (p->d_y) (void)hipFree(p->d_y);
     if (p->d_y2) (void)hipFree(p->d_y2);
     if (p->d_dop_tw) (void)hipFree(p->d_dop_tw);
@@ -244,6 +262,7 @@ static int run_segments(prc_caf_plan* p, const void* ref, const void* srv, int64
     a.srv = (const float2*)srv + (int64_t)f0 * frame_stride;
     a.window = window;
     a.taps = p->d_taps;
+    a.taps_rev = p->d_taps_rev;
     a.frame_stride = frame_stride;
     a.n = p->desc.n;
     a.n_valid = n_valid;
@@ -340,8 +359,10 @@ extern "C" int prc_caf_execute_multi(prc_caf_plan* p, const void* const* refs_ho
     std::lock_guard<std::mutex> lk(p->mtx);
     hipStream_t st = (hipStream_t)stream;
     const int64_t se = surf_elems(p);
-    const bool shared = p->multi == PRC_CAF_MULTI_SHARED && p->method == PRC_CAF_FFT4096 && p->doppler == PRC_DOPPLER_COLUMN &&
-                        nref > 1 && caf_team_multi_supported(p->desc.n, p->desc.range_bins, p->desc.freq_bins, p->ntaps, nref);
+    // SHARED: all illuminators in one launch; PAIRS: two per launch (a last odd one alone goes through the same kernel)
+    const int per = p->multi == PRC_CAF_MULTI_SHARED ? nref : (p->multi == PRC_CAF_MULTI_PAIRS ? 2 : 1);
+    const bool shared = per > 1 && p->method == PRC_CAF_FFT4096 && p->doppler == PRC_DOPPLER_COLUMN && nref > 1 &&
+                        caf_team_multi_supported(p->desc.n, p->desc.range_bins, p->desc.freq_bins, p->ntaps, per);
     if (!shared) {
         // one pass per illuminator (any method): same results, nothing shared
         for (int i = 0; i < nref; ++i) {
@@ -356,8 +377,8 @@ extern "C" int prc_caf_execute_multi(prc_caf_plan* p, const void* const* refs_ho
         }
         return PRC_OK;
     }
-    // frames in groups of g: surfaces [i * g + b] of the workspace, the surveillance pieces transformed once per
-    // segment for all illuminators
+    // frames in groups of g: surface (i, b) of a group at [i * nf + b] of the workspace; the surveillance pieces of a
+    // segment are transformed once per launch for the `per` illuminators it carries
     int g = p->group / nref;
     if (g < 1) g = 1;
     for (int f0 = 0; f0 < nframes; f0 += g) {
@@ -367,7 +388,7 @@ extern "C" int prc_caf_execute_multi(prc_caf_plan* p, const void* const* refs_ho
         a.srv = (const float2*)srv + (int64_t)f0 * frame_stride;
         a.window = window;
         a.taps = nullptr;
-        a.y = p->d_y2;
+        a.taps_rev = nullptr;
         a.frame_stride = frame_stride;
         a.n = p->desc.n;
         a.n_valid = n_valid;
@@ -377,13 +398,17 @@ extern "C" int prc_caf_execute_multi(prc_caf_plan* p, const void* const* refs_ho
         a.range_bins = p->desc.range_bins;
         a.freq_bins = p->desc.freq_bins;
         a.y_layout = PRC_Y_JK;
-        const float2* refs[PRC_CAF_MAX_REFS];
-        for (int i = 0; i < nref; ++i) refs[i] = (const float2*)refs_host[i] + (int64_t)f0 * frame_stride;
-        int rc = caf_launch_fft_team_multi(a, refs, nref, (int64_t)nf * se, nf, st);
-        if (rc) return rc;
+        for (int i0 = 0; i0 < nref; i0 += per) {
+            const int k = nref - i0 < per ? nref - i0 : per;
+            const float2* refs[PRC_CAF_MAX_REFS];
+            for (int i = 0; i < k; ++i) refs[i] = (const float2*)refs_host[i0 + i] + (int64_t)f0 * frame_stride;
+            a.y = p->d_y2 + (int64_t)i0 * nf * se;
+            int rc = caf_launch_fft_team_multi(a, refs, k, (int64_t)nf * se, nf, st);
+            if (rc) return rc;
+        }
         for (int i = 0; i < nref; ++i) {
-            rc = dop_launch(p->d_y2 + (int64_t)i * nf * se, (float2*)outs_host[i] + (int64_t)f0 * se, p->d_dop_tw,
-                            p->desc.freq_bins, p->desc.range_bins + 1, nf, st);
+            int rc = dop_launch(p->d_y2 + (int64_t)i * nf * se, (float2*)outs_host[i] + (int64_t)f0 * se, p->d_dop_tw,
+                                p->desc.freq_bins, p->desc.range_bins + 1, nf, st);
             if (rc) return rc;
         }
     }

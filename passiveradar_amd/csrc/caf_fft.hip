@@ -69,14 +69,19 @@ struct CafFftArgs {
 // third wavefront hides the load latency better than a register-hungry prefetch did at two (config 2, MI355X, A/B
 // on one box: 2.49 -> 2.32 ms per 256 frames).  With two lag blocks per pass the prefetching form at two
 // wavefronts per SIMD stays (three would spill).
-template <bool HAS_WIN, int NLB>
+// HAS_TAPS: a decimation FIR other than the boxcar (shortFilt=False, range_doppler_processing.py:73-78: flat-top low-pass of
+// 10 q + 1 taps): the same per-segment correlation with the weight of sample n of segment j being h[n_hi - n] w[n]
+// instead of w[n] -- segments of 10 q + 1 samples, ten-fold overlapped, one more 4-byte stream (the reversed taps) next to
+// the window.  Single-lag-block form only (up to 769 lags); wider spans stay on the time-domain kernel.
+template <bool HAS_WIN, int NLB, bool HAS_TAPS = false>
 __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_kernel(CafFftArgs a) {
+    static_assert(!HAS_TAPS || NLB == 1, "the long-FIR form is the single-lag-block kernel");
     constexpr bool PREFETCH = NLB != 1;
     // single-lag-block form: the surveillance loads of a piece are issued BEFORE the reference transform and fly under it
 #ifdef CAFF_LATE_V
     constexpr bool EARLY_V = false;
 #else
-    constexpr bool EARLY_V = NLB == 1;
+    constexpr bool EARLY_V = NLB == 1 && !HAS_TAPS;     // (a third 4-byte stream in flight: the registers are taken)
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* tab = reinterpret_cast<float2*>(smem_raw);
@@ -95,6 +100,7 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
     const float2* __restrict__ ref = a.s.ref + (int64_t)b * a.s.frame_stride;
     const float2* __restrict__ srv = a.s.srv + (int64_t)b * a.s.frame_stride;
     const float* __restrict__ win = a.s.window;
+    const float* __restrict__ trev = a.s.taps_rev;
     // frame-relative 32-bit arithmetic (n < 2^31); all of it is wave-uniform (SGPRs)
     const int N = (int)a.s.n, NV = (int)a.s.n_valid;
     const int R = a.s.range_bins;
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
         //   [u(i) resident] issue v0(i) | FFT u(i) | issue v1(i) / u(i+1) | FFT v0 | ... | acc
         float2 un[16];
         float wn[16];
+        float tn[HAS_TAPS ? 16 : 1];
         // nz: registers r >= nz lie beyond the piece for every lane (64 r >= cnt): not loaded, zero
         auto issue_u = [&](int n0, int nz = 16) {
 #ifdef CAFF_EXP_NOLOAD      // timing ablation only (wrong results): no global loads
@@ -147,7 +154,18 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
                     else wn[r] = 0.f;
                 }
             }
+            if (HAS_TAPS) {
+                const __amdgpu_buffer_rsrc_t rt = prc_rsrc(trev + (n0 - (int)n_lo64), clampu(cnt) * 4u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r < 8 || (r < 12 && nz > 8) || nz > 12) tn[r] = prc_buf_load_f32(rt, vo4, 256u * r);
+                    else tn[r] = 0.f;
+                }
+            }
         };
+        // weight of register r: window, taps, or their product
+        auto wgt = [&](int r) { return HAS_TAPS ? (HAS_WIN ? wn[r] * tn[r] : tn[r]) : wn[r]; };
+        constexpr bool WEIGHTED = HAS_WIN || HAS_TAPS;
         // srv slots [0, cnt+LB-1) of lag block lb: frame offsets start .. with circular wrap (:82)
         auto issue_v = [&](float2 (&v)[16], int n0, int cnt, int lb) {
 #ifdef CAFF_EXP_NOLOAD
@@ -189,7 +207,7 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
                 issue_u(n0, 8);
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    u[r] = r < 8 ? (HAS_WIN ? cscale(un[r], wn[r]) : un[r]) : make_float2(0.f, 0.f);
+                    u[r] = r < 8 ? (WEIGHTED ? cscale(un[r], wgt(r)) : un[r]) : make_float2(0.f, 0.f);
                 if (EARLY_V) issue_v(v[0], n0, cnt, lb0);
                 __builtin_amdgcn_sched_barrier(0);
                 fft1024_fwd<8>(u, tile, tab, f);
@@ -197,7 +215,7 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
                 issue_u(n0, 12);
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    u[r] = r < 12 ? (HAS_WIN ? cscale(un[r], wn[r]) : un[r]) : make_float2(0.f, 0.f);
+                    u[r] = r < 12 ? (WEIGHTED ? cscale(un[r], wgt(r)) : un[r]) : make_float2(0.f, 0.f);
                 if (EARLY_V) issue_v(v[0], n0, cnt, lb0);
                 __builtin_amdgcn_sched_barrier(0);
                 fft1024_fwd<12>(u, tile, tab, f);
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
                 if (!PREFETCH) issue_u(n0);
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    u[r] = HAS_WIN ? cscale(un[r], wn[r]) : un[r];
+                    u[r] = WEIGHTED ? cscale(un[r], wgt(r)) : un[r];
                 if (PREFETCH || EARLY_V) issue_v(v[0], n0, cnt, lb0);
                 __builtin_amdgcn_sched_barrier(0);
                 fft1024_fwd(u, tile, tab, f);
@@ -281,8 +299,9 @@ double caf_fft_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out) {
 
 bool caf_fft_supported(int64_t n, int range_bins, int freq_bins, int boxcar) {
     (void)freq_bins;
-    // n >= 2048 keeps a piece's 1024 slots from wrapping around the frame more than once
-    return boxcar && range_bins >= 1 && n >= 2048 && range_bins < n / 2;
+    // n >= 2048 keeps a piece's 1024 slots from wrapping around the frame more than once; a decimation FIR other than
+    // the boxcar runs on the single-lag-block kernel (up to 769 lags)
+    return range_bins >= 1 && n >= 2048 && range_bins < n / 2 && (boxcar || range_bins + 1 <= 769);
 }
 
 int caf_launch_fft(const CafSegArgs& s, int nframes, hipStream_t stream) {
@@ -294,7 +313,16 @@ int caf_launch_fft(const CafSegArgs& s, int nframes, hipStream_t stream) {
     if (rc) return rc;
     dim3 grid((unsigned)((s.freq_bins + CAFF_WAVES - 1) / CAFF_WAVES), (unsigned)nframes);
     const size_t lds = sizeof(float2) * (FFTW_TABLE + CAFF_WAVES * FFTW_TILE);
-    if (a.nlagblk == 1) {
+    if (s.taps_rev) {
+        PRC_REQUIRE(s.range_bins + 1 <= 769, PRC_EUNSUPPORTED, "caf_launch_fft: the long-FIR form takes up to 769 lags");
+        a.nlagblk = 1;
+        a.lagblk = s.range_bins + 1;
+        a.piece = FFTW_P + 1 - a.lagblk;
+        if (s.window)
+            hipLaunchKernelGGL((caf_fft_kernel<true, 1, true>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+        else
+            hipLaunchKernelGGL((caf_fft_kernel<false, 1, true>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+    } else if (a.nlagblk == 1) {
         if (s.window)
             hipLaunchKernelGGL((caf_fft_kernel<true, 1>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
         else

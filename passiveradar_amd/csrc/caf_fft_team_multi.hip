@@ -1,24 +1,29 @@
 // Cross-ambiguity segment sums of SEVERAL reference channels against one surveillance channel on the 4096-point
 // team FFT (fft_team.h); single-reference kernel and the algorithm: caf_fft_team.hip.
 //
-// This translation unit keeps the 16 per-thread T2 twiddles of the team transform in LDS (FT_TW2_LDS): the kernel
-// holds two surveillance spectra, the accumulator and one reference piece in registers and is at two wavefronts per
-// SIMD either way, which leaves 80 KB of LDS per workgroup -- room for the 32 KB table that buys back 32 VGPRs.
+// Round 4 form.  Two wavefronts per SIMD are given (V0, V1, the accumulator and one reference piece are 128 VGPRs), so
+// the kernel spends the registers and the LDS that occupancy leaves: T2 twiddles in registers, two exchange buffers
+// (FT_NBUF = 2: one workgroup barrier per forward transform, 71 KB of LDS, two workgroups per CU), every load issued one
+// transform ahead of its use (the second surveillance window under the first surveillance transform, reference piece
+// k + 1 under the transform of piece k), zero-padded reference pieces pruned as in the single-reference kernel (a piece
+// of at most 2048 / 3072 samples loads 8 / 12 registers per thread and skips their first-pass additions), packed-f32
+// butterflies (fft_pk.h).  Round 3's form (T2 twiddles in LDS, whole 16-register prefetch) spilled 27 VGPRs.
 #ifndef FT_NBUF
-#define FT_NBUF 1
+#define FT_NBUF 2
 #endif
 #include "caf_internal.h"
 #include "fft_team.h"
 #include "caf_team_tail.h"
+#include <type_traits>
 
 // ---- several reference channels against ONE surveillance channel (BASELINE config 5: four illuminators) ----------
 // fast_xambg is called once per (reference, surveillance) pair (range_doppler_processing.py:81-86 is the per-pair
 // unit), so the surveillance pieces of a segment are the same for every illuminator.  When a segment is at most two
 // pieces (configs 3 and 5), their spectra V0, V1 stay in registers while the illuminators take turns:
 //     per illuminator  U0, U1 forward, acc = conj(U0) V0 + conj(U1) V1, one inverse
-// = 2 + 3 nref transforms per segment instead of 5 nref (14 instead of 20 at config 5), the surveillance channel and
-// its lag-extended pieces read once.  Segments of more pieces go through the single-reference kernel once per
-// illuminator (same results, no sharing).
+// = 2 + 3 nref transforms per segment instead of 5 nref (14 instead of 20 at config 5; 8 instead of 10 for a pair), the
+// surveillance channel and its lag-extended pieces read once.  Segments of more pieces go through the single-reference
+// kernel once per illuminator (same results, no sharing).
 struct CafTeamMultiArgs {
     CafSegArgs s;                              // s.ref unused; s.y = surface block of illuminator 0
     const float2* gtab;
@@ -36,7 +41,12 @@ __device__ __forceinline__ float2 cmul_conj_a(float2 u, float2 v) {
     return make_float2(fmaf(u.y, v.y, u.x * v.x), fmaf(-u.y, v.x, u.x * v.y));
 }
 
-template <bool HAS_WIN>
+template <int N> using caft_int = std::integral_constant<int, N>;
+
+// NZ0 / NZ1: registers per thread that a first / second reference piece can fill (256 NZ >= its samples), fixed per launch
+// by the host from the piece length and the segment length: (8, 8) at config 5, (12, 8) at config 3, (16, 16) otherwise.
+// A shorter piece (first and last segments of a frame) reads zeros beyond its end through the range check.
+template <bool HAS_WIN, int NZ0, int NZ1>
 __global__ __launch_bounds__(FT_THREADS, CAFT_MULTI_WAVES) void caf_fft_team_multi_kernel(CafTeamMultiArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_MULTI_WAVES) void caf_fft_team_mul
         const bool two = cnt1 > 0;
 
         for (int lb = 0; lb < a.nlagblk; ++lb) {
-            auto load_v = [&](float2 (&v)[16], int n0, int cnt) {
+            auto issue_v = [&](float2 (&v)[16], int n0, int cnt) {
                 int start = n0 + lb * LB;
                 if (start >= N) start -= N;
                 const int want = cnt + LB - 1;
@@ -92,83 +102,78 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_MULTI_WAVES) void caf_fft_team_mul
                     }
                 }
             };
-#ifndef CAFT_MULTI_PREFETCH
-            auto load_u = [&](float2 (&u)[16], const float2* __restrict__ ref, int n0, int cnt) {
+            // reference piece one transform ahead: the raw samples and the window land in un / wn; registers beyond the
+            // piece (r >= NZ) are not loaded
+            constexpr int NZM = NZ0 > NZ1 ? NZ0 : NZ1;
+            // pieces of at most 2048 samples (config 5) are loaded one transform ahead (24 VGPRs in flight); longer ones
+            // (config 3's 3072-sample piece is 36) would spill next to V0, V1, the accumulator and the piece in work, and
+            // are loaded where they are used
+#ifdef CAFT_MULTI_NO_AHEAD
+            constexpr bool AHEAD = false;
+#else
+            constexpr bool AHEAD = NZM <= 8;
+#endif
+            float2 un[NZM];
+            float wn[NZM];
+            auto issue_u = [&](auto nzc, const float2* __restrict__ ref, int n0, int cnt) {
+                constexpr int NZ = decltype(nzc)::value;
                 if (NV - n0 < cnt) cnt = NV - n0;
                 const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + n0, clampu(cnt) * 8u);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) u[r] = prc_buf_load_c64(ru, vo8, 2048u * r);
+                for (int r = 0; r < NZ; ++r) un[r] = prc_buf_load_c64(ru, vo8, 2048u * r);
                 if (HAS_WIN) {
                     const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + n0, clampu(cnt) * 4u);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float w = prc_buf_load_f32(rw, vo4, 1024u * r);
-                        u[r].x *= w;
-                        u[r].y *= w;
-                    }
+                    for (int r = 0; r < NZ; ++r) wn[r] = prc_buf_load_f32(rw, vo4, 1024u * r);
                 }
             };
-#endif
+            // u = w * (landed piece), zero beyond it
+            auto take_u = [&](auto nzc, float2 (&u)[16]) {
+                constexpr int NZ = decltype(nzc)::value;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r < NZ) u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
+                    else u[r] = make_float2(0.f, 0.f);
+                }
+            };
             float2 v0[16], v1[16];
             // buffer schedule (fft_team.h: transforms alternate exchange buffers 0, 1, 0, ...; a sequence that restarts
             // at buffer 0 is separated by ft_team_sync()):  V0<0> V1<1> sync | U0<0> U1<1> inv<0> sync | ...
-            load_v(v0, lo, cnt0);
+            issue_v(v0, lo, cnt0);
+            if (two) issue_v(v1, n1p, cnt1);                    // flies under the transform of V0
+            __builtin_amdgcn_sched_barrier(0);
             ft4096_fwd<0>(v0, f);
-            if (two) {                                          // uniform
-                load_v(v1, n1p, cnt1);
-                ft4096_fwd<1>(v1, f);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (AHEAD) issue_u(caft_int<NZ0>(), a.refs[0] + (int64_t)b * a.s.frame_stride, lo, cnt0);   // ... and the first reference piece under V1
+            __builtin_amdgcn_sched_barrier(0);
+            if (two) ft4096_fwd<1>(v1, f);
             if (FT_NBUF == 2) ft_team_sync();
             const int L0 = lb * LB;
-#ifdef CAFT_MULTI_PREFETCH
-            // the reference pieces arrive one transform ahead of their use: the loads of step (i, piece) + 1 are issued
-            // before the transform of step (i, piece); past the last illuminator the descriptor is empty
-            float2 un[16];
-            float wn[16];
-            auto issue_u = [&](const float2* __restrict__ ref, int n0, int cnt) {
-                if (NV - n0 < cnt) cnt = NV - n0;
-                const __amdgpu_buffer_rsrc_t ru = prc_rsrc(ref + n0, clampu(cnt) * 8u);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) un[r] = prc_buf_load_c64(ru, vo8, 2048u * r);
-                if (HAS_WIN) {
-                    const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + n0, clampu(cnt) * 4u);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) wn[r] = prc_buf_load_f32(rw, vo4, 1024u * r);
-                }
-            };
-            issue_u(a.refs[0] + (int64_t)b * a.s.frame_stride, lo, cnt0);
-#endif
             for (int i = 0; i < a.nref; ++i) {
                 const float2* __restrict__ ref = a.refs[i] + (int64_t)b * a.s.frame_stride;
                 float2* __restrict__ yrow = a.s.y + (int64_t)i * a.y_ref_stride +
                                             ((int64_t)b * a.s.freq_bins + j) * (R + 1);
-                float2 u[16], acc[16];
-#ifdef CAFT_MULTI_PREFETCH
                 const bool more = i + 1 < a.nref;
                 const float2* __restrict__ refn = a.refs[more ? i + 1 : i] + (int64_t)b * a.s.frame_stride;
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
-                if (two) issue_u(ref, n1p, cnt1);
-                else issue_u(refn, lo, more ? cnt0 : 0);
-#else
-                load_u(u, ref, lo, cnt0);
-#endif
+                float2 u[16], acc[16];
+                // piece 0: take what landed, issue the next piece (this illuminator's second, or the next one's first;
+                // past the last illuminator an empty descriptor), transform
+                if (!AHEAD) issue_u(caft_int<NZ0>(), ref, lo, cnt0);
+                take_u(caft_int<NZ0>(), u);
+                if (AHEAD) {
+                    if (two) issue_u(caft_int<NZ1>(), ref, n1p, cnt1);
+                    else issue_u(caft_int<NZ0>(), refn, lo, more ? cnt0 : 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                ft4096_fwd<0>(u, f);
+                ft4096_fwd<0, NZ0>(u, f);
 #pragma unroll
                 for (int m = 0; m < 16; ++m) acc[m] = cmul_conj_a(u[m], v0[m]);
                 if (two) {
-#ifdef CAFT_MULTI_PREFETCH
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        u[r] = HAS_WIN ? make_float2(un[r].x * wn[r], un[r].y * wn[r]) : un[r];
-                    issue_u(refn, lo, more ? cnt0 : 0);
-#else
-                    load_u(u, ref, n1p, cnt1);
-#endif
+                    if (!AHEAD) issue_u(caft_int<NZ1>(), ref, n1p, cnt1);
+                    take_u(caft_int<NZ1>(), u);
+                    if (AHEAD) issue_u(caft_int<NZ0>(), refn, lo, more ? cnt0 : 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    ft4096_fwd<1>(u, f);
+                    ft4096_fwd<1, NZ1>(u, f);
 #pragma unroll
                     for (int m = 0; m < 16; ++m) cmac_conj_a(acc[m], u[m], v1[m]);
                     ft4096_inv<0>(acc, f);
@@ -234,12 +239,28 @@ int caf_launch_fft_team_multi(const CafSegArgs& s, const float2* const* refs, in
     a.segs = total >= 16384 ? 4 : (total >= 4096 ? 2 : 1);
     dim3 grid((unsigned)((s.freq_bins + a.segs - 1) / a.segs), (unsigned)nframes);
     const size_t lds = sizeof(float2) * FT_LDS_ELEMS;
-    { int rc_ = prc_lds_optin(reinterpret_cast<const void*>(s.window ? &caf_fft_team_multi_kernel<true>
-                                                                       : &caf_fft_team_multi_kernel<false>), (int)lds); if (rc_) return rc_; }
-    if (s.window)
-        hipLaunchKernelGGL((caf_fft_team_multi_kernel<true>), grid, dim3(FT_THREADS), lds, stream, a);
-    else
-        hipLaunchKernelGGL((caf_fft_team_multi_kernel<false>), grid, dim3(FT_THREADS), lds, stream, a);
+    // the longest first / second piece of a segment (s.ntaps samples: pieces of a.piece, a tail of <= CAFT_TAIL_MAX direct)
+    auto nz_of = [](int64_t cnt) { return cnt <= 2048 ? 8 : (cnt <= 3072 ? 12 : 16); };
+    int64_t rest = (int64_t)s.ntaps - a.piece;
+    if (rest <= CAFT_TAIL_MAX) rest = 0;
+    const int nz0 = nz_of(s.ntaps < a.piece ? s.ntaps : a.piece), nz1 = rest > 0 ? nz_of(rest) : 8;
+    const dim3 block(FT_THREADS);
+#define CAFT_MULTI_LAUNCH(W, A, B)                                                                                 \
+    do {                                                                                                           \
+        rc = prc_lds_optin(reinterpret_cast<const void*>(&caf_fft_team_multi_kernel<W, A, B>), (int)lds);          \
+        if (rc) return rc;                                                                                         \
+        hipLaunchKernelGGL((caf_fft_team_multi_kernel<W, A, B>), grid, block, lds, stream, a);                     \
+    } while (0)
+    if (s.window) {
+        if (nz0 == 8 && nz1 == 8) CAFT_MULTI_LAUNCH(true, 8, 8);
+        else if (nz0 == 12 && nz1 == 8) CAFT_MULTI_LAUNCH(true, 12, 8);
+        else CAFT_MULTI_LAUNCH(true, 16, 16);
+    } else {
+        if (nz0 == 8 && nz1 == 8) CAFT_MULTI_LAUNCH(false, 8, 8);
+        else if (nz0 == 12 && nz1 == 8) CAFT_MULTI_LAUNCH(false, 12, 8);
+        else CAFT_MULTI_LAUNCH(false, 16, 16);
+    }
+#undef CAFT_MULTI_LAUNCH
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }

@@ -11,6 +11,7 @@ struct CafSegArgs {
     const float2* srv;
     const float* window;   // float32[n] or nullptr
     const float* taps;     // float32[ntaps] or nullptr (boxcar)
+    const float* taps_rev; // the same taps in reverse order (tap of sample n of segment j at [n - n_lo]): FFT kernels
     float2* y;             // slow-time buffer
     int64_t frame_stride;  // elements between consecutive frames in ref/srv
     int64_t n;             // CPI length (circular-wrap modulus)
@@ -45,8 +46,6 @@ double caf_fft_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out);
 // nref reference channels against one surveillance channel in one launch (segments of <= 2 pieces): illuminator i's
 // surfaces go to y + i * y_ref_stride
 #define PRC_CAF_MAX_REFS 8
-// what PRC_CAF_MULTI_AUTO means when nobody said otherwise: the mode measured fastest on MI355X
-#define PRC_CAF_MULTI_DEFAULT PRC_CAF_MULTI_TURNS
 int caf_launch_fft_team_multi(const CafSegArgs& a, const float2* const* refs, int nref, int64_t y_ref_stride,
                               int nframes, hipStream_t stream);
 bool caf_team_multi_supported(int64_t n, int range_bins, int freq_bins, int64_t q1, int nref);

@@ -47,8 +47,8 @@ def caf_plan_for(n, rangeBins, freqBins, shortFilt=True, max_frames=1, method=No
                  multi=_lib.CAF_MULTI_AUTO):
     method = _DEFAULTS["caf"] if method is None else method
     doppler = _DEFAULTS["doppler"] if doppler is None else doppler
-    if not shortFilt and method in (_lib.CAF_FFT, _lib.CAF_FFT4096):
-        method = _lib.CAF_AUTO          # the long FIR only exists in the time-domain kernel
+    if not shortFilt and (method == _lib.CAF_FFT4096 or (method == _lib.CAF_FFT and rangeBins + 1 > 769)):
+        method = _lib.CAF_AUTO          # the long FIR runs on the 1024-point FFT kernel up to 769 lags, else time-domain
     q = int(n / freqBins) if freqBins else 0
     multi = _lib.CAF_MULTI_MODES[multi] if isinstance(multi, str) else int(multi)
     # plans copy the process-wide options when they are made: a cached plan must not outlive a change of them

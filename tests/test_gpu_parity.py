@@ -862,3 +862,26 @@ def test_caf_cfg5_digest_multi(mode):
         assert np.abs(out.ravel()[g[f"ill{i}_top_idx"]] - g[f"ill{i}_top_val"]).max() / peak < TOL, i
         assert np.abs(out.sum(axis=0) - g[f"ill{i}_col_sums"]).max() / (peak * np.sqrt(F)) < TOL, i
         assert np.abs(out.sum(axis=1) - g[f"ill{i}_row_sums"]).max() / (peak * np.sqrt(R + 1)) < TOL, i
+
+
+@pytest.mark.parametrize("method", ["fft", "direct"])
+def test_caf_long_filter_at_config1_size(method):
+    """fast_xambg(..., shortFilt=False) at a BASELINE size (config 1: N = 262 144, 257 lags, 256 Doppler bins, q = 1024:
+    the flat-top decimation FIR of 10 241 taps, range_doppler_processing.py:73-78) against the reference's own surface
+    (golden caf_longfilt_cfg1), on the FFT segment kernel's long-FIR form and on the time-domain kernel"""
+    from scipy.signal import get_window
+    from passiveradar_amd import range_doppler_processing as rdp
+    g = load_golden("caf_longfilt_cfg1")
+    n, R, F = int(g["N"]), int(g["R"]), int(g["F"])
+    ref, srv = scene.make_scene(n, float(g["fs"]), R, int(g["seed"]))
+    rdp.set_default_methods(caf={"direct": 1, "fft": 2}[method])
+    try:
+        plan = rdp.caf_plan_for(n, R, F, shortFilt=False)
+        assert plan.method == {"direct": 1, "fft": 2}[method]
+        out = rdp.fast_xambg(ref, srv, R, F, n, get_window(("kaiser", 5.0), n), shortFilt=False)[:, :, 0]
+    finally:
+        rdp.set_default_methods(caf=0)
+    assert rel_err(out, g["out"]) < TOL
+    # AUTO takes the FFT form for a long FIR up to 769 lags, the time-domain kernel beyond
+    assert rdp.caf_plan_for(n, R, F, shortFilt=False).method == 2
+    assert rdp.caf_plan_for(n, 1024, F, shortFilt=False).method == 1

@@ -345,6 +345,37 @@ def test_bench_cfg4_maps_against_an_independent_pass(tmp_path):
     assert rel_err(got[list(d["frame_index"]).index(fi)], exp) < 1e-4
 
 
+def test_bench_default_workload_maps_against_an_independent_pass(tmp_path):
+    """The HEADLINE path itself: bench.py's default workload at 600 frames -- three sub-batches of 256 (the
+    last one ragged) alternating over the three LS plans / streams, the CAF on a fourth -- dumps the first, second, middle
+    and last map and every frame's sum of its last timed step; an independent pass over the regenerated stream (batches of
+    five, LS and CAF back to back on one stream, one plan) must give the same maps"""
+    import subprocess
+    import sys
+    import torch
+    from passiveradar_amd.stream import HipBackend
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    dump = str(tmp_path / "cfg2.npz")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--no-cpu", "--steps", "2", "--warmup", "1",
+                        "--frames", "600", "--dump", dump], capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = np.load(dump)
+    fs, n, R, F, _, _ = bench.WORKLOADS["cfg2"]
+    C, nfr = n // 2, int(d["nframes"])
+    assert nfr == 600 and list(d["frame_index"]) == [0, 1, 300, 599]
+    dev = torch.device("cuda", 0)
+    ref_pad, srv_pad = bench.synth_padded(torch, nfr, C, fs, R, int(d["seed0"]), dev)     # the stream as bench.py builds it
+    be = HipBackend(n, R, F, fs, batch=5, overlap=False)
+    maps = be.run(ref_pad, srv_pad, nfr, 0, nfr)
+    torch.cuda.synchronize()
+    got = d["ill0_frames"]
+    for j, fi in enumerate(d["frame_index"]):
+        assert rel_err(got[j], maps[int(fi)].cpu().numpy()) < 1e-6, int(fi)
+    assert rel_err(d["ill0_sums"], maps.sum(dim=(1, 2)).cpu().numpy()) < 1e-5
+
+
 def test_stream_with_the_ls_filter_variant():
     """SURVEY 8's config-2 "LS_Filter variant": the stream backend with clutter="ls_direct" runs LS_Filter
     (clutter_removal.py:6-56: circular data matrix, reg = 1 on the Gram diagonal) per hop chunk, then the overlapped
@@ -412,7 +443,7 @@ def test_prconfig_raw_to_frame_against_reference_output():
     from passiveradar_amd import scene
     from passiveradar_amd.stream import HipBackend, StreamProcessor
     g = load_golden("pipeline_prconfig_raw")
-    cfg = {k[4:]: (float(g[k]) if k == "cfg_IF_sample_rate" else int(g[k])) for k in g.files if k.startswith("cfg_")}
+    cfg = {k[4:]: (float(g[k]) if k == "cfg_IF_sample_rate" else int(g[k])) for k in g if k.startswith("cfg_")}
     raw_ref, raw_srv = scene.make_raw_stream(int(g["nblk"]), cfg["input_chunk_length"], cfg["input_sample_rate"],
                                              cfg["offset_freq"], int(g["seed"]))
     if (list(scene.raw_checksum(raw_ref)) != [int(v) for v in g["raw_ref_checksum"]] or

@@ -253,7 +253,13 @@ def test_plan_cache_evicts_with_close():
     assert closed == [0, 1]
 
 
-@pytest.mark.parametrize("tag", ["r01", "r02"])
+def _committed_bench_tags():
+    import glob
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    return sorted(os.path.basename(p)[:3] for p in glob.glob(os.path.join(here, "r??_bench_default.json")))
+
+
+@pytest.mark.parametrize("tag", _committed_bench_tags())          # every round's committed line, r01 .. the latest
 def test_committed_bench_line_follows_the_contract(tag):
     """profiles/rNN_bench_default.json is bench.py's own output on the GPU box; the driver's contract fields must be there"""
     import json

@@ -334,3 +334,13 @@ def test_prconfig_raw_to_frame_restatement():
     frames, cleaned = O.process_stream(a, s, n, R, F, fs, return_cleaned=True)
     assert np.abs(cleaned[::61] - g["cleaned_sub"]).max() / float(g["if_srv_rms"]) < 1e-4
     assert rel_err(frames[:, :, int(g["frame_index"])], g["out"]) < 1e-4
+
+
+def test_caf_long_filter_at_config1_size():
+    """shortFilt=False at config-1 size (10 241-tap flat-top decimation FIR): the oracle against the reference's surface"""
+    from scipy.signal import get_window
+    g = load_golden("caf_longfilt_cfg1")
+    n, R, F = int(g["N"]), int(g["R"]), int(g["F"])
+    ref, srv = scene.make_scene(n, float(g["fs"]), R, int(g["seed"]))
+    out = O.fast_xambg(ref, srv, R, F, n, get_window(("kaiser", 5.0), n), shortFilt=False)[:, :, 0]
+    assert rel_err(out, g["out"]) < 1e-5

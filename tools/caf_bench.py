@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--group-mb", type=int, default=None)
     ap.add_argument("--multi", default="auto", choices=["auto", "turns", "shared", "pairs"])
     ap.add_argument("--tag", default="")
+    ap.add_argument("--long-fir", action="store_true", help="shortFilt=False: firwin(10 q + 1, 1/q, flattop) instead of the boxcar")
     args = ap.parse_args()
     import torch
     from passiveradar_amd import _lib, engine
@@ -46,7 +47,12 @@ def main():
     refs = [mk() for _ in range(nref)]
     srv = mk()
     win = torch.from_numpy(np.kaiser(n, 5.0).astype(np.float32)).to(dev)
-    plan = engine.CafPlan(n, R, F, nf * nref, args.caf_method, args.doppler, multi=args.multi)
+    taps = None
+    if args.long_fir:
+        from scipy.signal import firwin
+        q = n // F
+        taps = firwin(10 * q + 1, 1.0 / q, window="flattop").astype(np.float32)
+    plan = engine.CafPlan(n, R, F, nf * nref, args.caf_method, args.doppler, taps=taps, multi=args.multi)
     outs = [torch.empty((nf, F, R + 1), dtype=torch.complex64, device=dev) for _ in range(nref)]
     s = _lib.torch_stream_ptr()
     ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -65,7 +71,7 @@ def main():
         return float(np.median(ts))
 
     res = {"lib": os.environ.get("PRCORE_LIB", "default"), "tag": args.tag, "shape": args.shape, "frames": nf,
-           "nref": nref, "method": plan.method, "doppler": plan.doppler, "multi": plan.multi}
+           "nref": nref, "long_fir": bool(args.long_fir), "method": plan.method, "doppler": plan.doppler, "multi": plan.multi}
     res["segments_ms"] = timeit(lambda: plan.execute_segments(refs[0], srv, nf, C, n, win, s))
     res["doppler_ms"] = timeit(lambda: plan.execute_doppler(outs[0], nf, s))
     res["execute_ms"] = timeit(lambda: plan.execute(refs[0], srv, outs[0], nf, C, n, win, s))
