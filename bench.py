@@ -676,6 +676,12 @@ def main():
             fir_bytes = 24.0 * C + (16.0 * C * (nb_bins - 1) / nb_bins if fused else 0.0)
             kt["ls_fir_subtract"] = {"ms": acc[2] / k3[2], "launches_per_step": k3[2] * execs, "bound": "hbm",
                                      "work": nb_ls * fir_bytes}
+            if fused:
+                # what the fused kernel HAS to move per chunk-bin: the cached block spectrum (P complex64
+                # per P - E new samples), the stream in and the stream out -- against SURVEY 8d's 24C + 16C (4/5) that the
+                # roofline object is priced on (the fusion removes the separate correlation pass, so it moves fewer bytes)
+                cache_per_sample = 32768.0 / (4096 - ((T - 1 + 15) & ~15)) if (T >= 250 and C >= 65536) else 8192.0 / (1025 - T)
+                kt["ls_fir_subtract"]["compulsory_work"] = nb_ls * (16.0 + cache_per_sample) * C
         elif clutter == "nlms":
             a, b = ev(), ev()
             a.record()
@@ -713,6 +719,11 @@ def main():
                     traffic = None
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc}
+            if "compulsory_work" in d:
+                # the same launch priced on the bytes the fused form cannot avoid (real traffic, PMC: the same to 2 %)
+                roof["achieved_compulsory_bytes"] = d["compulsory_work"] / (d["ms"] * 1e-3) / 1e9
+                roof["frac_compulsory_bytes"] = roof["achieved_compulsory_bytes"] / HBM_PEAK_GBS
+                roof["frac_compulsory_bytes_of_copy_ceiling"] = roof["achieved_compulsory_bytes"] / 6290.0
         caf_bytes = 20.0 * n + 8.0 * F * (R + 1)
         if nill > 1:                                            # srv and the window are shared by the illuminators
             per_frame_bytes = nill * 8.0 * n + 8.0 * n + 4.0 * n + nill * 8.0 * F * (R + 1)

@@ -71,7 +71,10 @@ typedef enum prc_option {
                                      that would fit one wavefront over 2 / 4 (latency experiments)                        */
     PRC_OPT_LS_CACHE_LIMIT_MB = 5,/* > 0: an LS plan does not allocate a spectrum cache larger than this many MiB and runs
                                      the recomputing / per-bin kernels instead; default 0 = no limit                      */
-    PRC_OPT_COUNT_ = 6
+    PRC_OPT_NLMS_WG_WAVES = 6,    /* 0 (default): NLMS wavefronts (= independent streams) per workgroup / CU from the stream count
+                                     and the measured step times; 4 / 8 / 12 / 16: forced (16 = four per SIMD exists for the
+                                     config-3 filter length only; A/B runs)                                                */
+    PRC_OPT_COUNT_ = 7
 } prc_option;
 int prc_set_option(int32_t option, int64_t value);     /* PRC_EINVAL for an unknown option or a value out of range */
 int prc_get_option(int32_t option, int64_t* value);

@@ -29,6 +29,8 @@ struct prc_caf_plan {
     float2* d_y = nullptr;           // [k][j]-ordered slow-time buffer of the rocFFT path, max_frames * F * (R+1)
     float2* d_y2 = nullptr;          // [j][k]-ordered slow-time buffer written row-wise by the segment kernels
     float2* d_dop_tw = nullptr;      // W_F^m table of the column-FFT Doppler kernel
+    int y_kt = 0;                    // column-FFT Doppler path: the slow-time buffer is tiled by this many columns (0: plain rows)
+    int64_t y_surf = 0;              // elements per surface of the slow-time buffer
     int group = 1;                   // surfaces per segment/Doppler round of prc_caf_execute
     int multi = PRC_CAF_MULTI_TURNS; // resolved prc_caf_multi_mode of prc_caf_execute_multi
     size_t y_bytes = 0;
@@ -170,7 +172,13 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
     }
     int rc = PRC_OK;
     auto fail = [&](int code) { prc_caf_plan_destroy(p); return code; };
-    p->y_bytes = sizeof(float2) * (size_t)d->max_frames * d->freq_bins * (d->range_bins + 1);
+    // the column-FFT Doppler kernel reads tiles of KT columns x F rows: the segment kernels write them contiguously
+    p->y_kt = p->doppler == PRC_DOPPLER_COLUMN ? dop_tile_cols(d->freq_bins) : 0;
+    {
+        const int64_t cols = d->range_bins + 1;
+        p->y_surf = p->y_kt ? (int64_t)d->freq_bins * ((cols + p->y_kt - 1) / p->y_kt) * p->y_kt : (int64_t)d->freq_bins * cols;
+    }
+    p->y_bytes = sizeof(float2) * (size_t)d->max_frames * (size_t)p->y_surf;
     p->group = pick_group(d);
     const bool rowwise = p->method == PRC_CAF_FFT || p->method == PRC_CAF_FFT4096 || p->doppler == PRC_DOPPLER_COLUMN;
     if (p->doppler == PRC_DOPPLER_ROCFFT && hipMalloc(&p->d_y, p->y_bytes) != hipSuccess) {
@@ -271,7 +279,9 @@ static int run_segments(prc_caf_plan* p, const void* ref, const void* srv, int64
     a.half = p->half;
     a.range_bins = p->desc.range_bins;
     a.freq_bins = p->desc.freq_bins;
-    const int64_t off = (int64_t)s0 * surf_elems(p);
+    a.y_kt = p->y_kt;
+    a.y_surface = p->y_surf;
+    const int64_t off = (int64_t)s0 * p->y_surf;
     if (p->method == PRC_CAF_FFT || p->method == PRC_CAF_FFT4096) {
         // the FFT kernels write whole rows y[j][0..R] (coalesced)
         a.y = p->d_y2 + off;
@@ -292,7 +302,7 @@ static int run_doppler(prc_caf_plan* p, void* out, int s0, int ns, hipStream_t s
     PRC_REQUIRE(out, PRC_EINVAL, "prc_caf_execute: null output");
     const int F = p->desc.freq_bins, cols = p->desc.range_bins + 1;
     if (p->doppler == PRC_DOPPLER_COLUMN)
-        return dop_launch(p->d_y2 + (int64_t)s0 * surf_elems(p), (float2*)out, p->d_dop_tw, F, cols, ns, stream);
+        return dop_launch(p->d_y2 + (int64_t)s0 * p->y_surf, p->y_surf, (float2*)out, p->d_dop_tw, F, cols, ns, stream);
     // rocFFT: the plan is batched for max_frames and always transforms the whole buffer (one plan per shape); the
     // surfaces outside [s0, s0 + ns) are transformed in place too, so this path takes whole batches only
     PRC_REQUIRE(s0 == 0, PRC_EINVAL, "prc_caf_execute: the rocFFT Doppler path transforms whole batches");
@@ -398,17 +408,19 @@ extern "C" int prc_caf_execute_multi(prc_caf_plan* p, const void* const* refs_ho
         a.range_bins = p->desc.range_bins;
         a.freq_bins = p->desc.freq_bins;
         a.y_layout = PRC_Y_JK;
+        a.y_kt = p->y_kt;
+        a.y_surface = p->y_surf;
         for (int i0 = 0; i0 < nref; i0 += per) {
             const int k = nref - i0 < per ? nref - i0 : per;
             const float2* refs[PRC_CAF_MAX_REFS];
             for (int i = 0; i < k; ++i) refs[i] = (const float2*)refs_host[i0 + i] + (int64_t)f0 * frame_stride;
-            a.y = p->d_y2 + (int64_t)i0 * nf * se;
-            int rc = caf_launch_fft_team_multi(a, refs, k, (int64_t)nf * se, nf, st);
+            a.y = p->d_y2 + (int64_t)i0 * nf * p->y_surf;
+            int rc = caf_launch_fft_team_multi(a, refs, k, (int64_t)nf * p->y_surf, nf, st);
             if (rc) return rc;
         }
         for (int i = 0; i < nref; ++i) {
-            int rc = dop_launch(p->d_y2 + (int64_t)i * nf * se, (float2*)outs_host[i] + (int64_t)f0 * se, p->d_dop_tw,
-                                p->desc.freq_bins, p->desc.range_bins + 1, nf, st);
+            int rc = dop_launch(p->d_y2 + (int64_t)i * nf * p->y_surf, p->y_surf, (float2*)outs_host[i] + (int64_t)f0 * se,
+                                p->d_dop_tw, p->desc.freq_bins, p->desc.range_bins + 1, nf, st);
             if (rc) return rc;
         }
     }

@@ -11,7 +11,7 @@
 // (b % 8) * per_xcd + b / 8, so an XCD works through one contiguous run of tiles -- neighbouring tiles split 128-byte
 // lines of y and out between them.
 template <int F>
-__global__ __launch_bounds__(DopCfg<F>::THREADS) void doppler_col_kernel(const float2* __restrict__ y,
+__global__ __launch_bounds__(DopCfg<F>::THREADS) void doppler_col_kernel(const float2* __restrict__ y, int64_t y_surface,
                                                                          float2* __restrict__ out,
                                                                          const float2* __restrict__ tw, int cols,
                                                                          int tiles, int total) {
@@ -24,20 +24,21 @@ __global__ __launch_bounds__(DopCfg<F>::THREADS) void doppler_col_kernel(const f
     const int frame = work / tiles, tile = work - frame * tiles;
     const int c = threadIdx.x % KT, p = threadIdx.x / KT;
     const int k = tile * KT + c;
-    // Raw buffer accesses: the per-frame base is uniform, a thread's part of the offset is ONE 32-bit VGPR, and the
-    // register's part (row r Q of the loads, the fftshift-ed output row of register m of the stores) is a uniform
-    // soffset -- no 64-bit per-lane addresses.  Columns beyond the surface get an out-of-range offset: their loads
-    // return zero and their stores are dropped by the hardware range check.
+    // Raw buffer accesses: bases are uniform, a thread's part of the offset is ONE 32-bit VGPR per side, and the register's
+    // part (row r Q of the loads, the fftshift-ed output row of register m of the stores) is a uniform soffset -- no 64-bit
+    // per-lane addresses.  Loads: the tile is a contiguous block of F rows of KT samples (columns of the last tile beyond
+    // the surface hold whatever the buffer held: every column is transformed on its own and those are never stored).
+    // Stores: columns beyond the surface get an out-of-range offset and are dropped by the hardware range check.
     const unsigned row_bytes = (unsigned)cols * 8u;
-    const unsigned ld_thread = (unsigned)p * row_bytes;                              // row p of the tile's column
+    const unsigned ld_thread = (unsigned)(p * KT + c) * 8u;                          // row p, column c of the tile
     const unsigned st_thread = (unsigned)((p / F3) + 16 * (p % F3) * E) * row_bytes;  // row k1 + 16 g E
     const unsigned limit = 0xFFFFFFF0u - 2u * (unsigned)F * row_bytes;
-    const unsigned cb = k < cols ? (unsigned)k * 8u : 0xFFFFFFF8u - ld_thread - st_thread;
-    const __amdgpu_buffer_rsrc_t ry = prc_rsrc(y + (int64_t)frame * F * cols, limit);
+    const unsigned cb = k < cols ? (unsigned)k * 8u : 0xFFFFFFF8u - st_thread;
+    const __amdgpu_buffer_rsrc_t ry = prc_rsrc(y + (int64_t)frame * y_surface + (int64_t)tile * F * KT, (unsigned)(F * KT) * 8u);
     const __amdgpu_buffer_rsrc_t ro = prc_rsrc(out + (int64_t)frame * F * cols, limit);
     float2 x[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = prc_buf_load_c64(ry, ld_thread + cb, (unsigned)(r * Q) * row_bytes);
+    for (int r = 0; r < 16; ++r) x[r] = prc_buf_load_c64(ry, ld_thread, (unsigned)(r * Q * KT) * 8u);
     const DopTw t = dop_load_twiddles<F>(tw, p);
     dop_stage1<F>(x, t);
     if (!DopCfg<F>::SPLIT) {
@@ -99,8 +100,19 @@ bool dop_supported(int F, int cols) {
     return 3.0 * (double)F * (double)cols * 8.0 < 4294967280.0;
 }
 
+int dop_tile_cols(int F) {
+    switch (F) {
+        case 256: return DopCfg<256>::KT;
+        case 512: return DopCfg<512>::KT;
+        case 1024: return DopCfg<1024>::KT;
+        case 2048: return DopCfg<2048>::KT;
+        case 4096: return DopCfg<4096>::KT;
+    }
+    return 0;
+}
+
 template <int F>
-static int dop_launch_t(const float2* y, float2* out, const float2* tw, int cols, int nframes, hipStream_t stream) {
+static int dop_launch_t(const float2* y, int64_t y_surface, float2* out, const float2* tw, int cols, int nframes, hipStream_t stream) {
     constexpr int KT = DopCfg<F>::KT;
     const size_t lds = DopCfg<F>::LDS_BYTES;
     static bool attr_done[16] = {false};
@@ -113,19 +125,19 @@ static int dop_launch_t(const float2* y, float2* out, const float2* tw, int cols
     }
     const int tiles = (cols + KT - 1) / KT, total = tiles * nframes;
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
-    hipLaunchKernelGGL((doppler_col_kernel<F>), grid, dim3(DopCfg<F>::THREADS), lds, stream, y, out, tw, cols, tiles,
-                       total);
+    hipLaunchKernelGGL((doppler_col_kernel<F>), grid, dim3(DopCfg<F>::THREADS), lds, stream, y, y_surface, out, tw, cols,
+                       tiles, total);
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }
 
-int dop_launch(const float2* y, float2* out, const float2* tw, int F, int cols, int nframes, hipStream_t stream) {
+int dop_launch(const float2* y, int64_t y_surface, float2* out, const float2* tw, int F, int cols, int nframes, hipStream_t stream) {
     switch (F) {
-        case 256: return dop_launch_t<256>(y, out, tw, cols, nframes, stream);
-        case 512: return dop_launch_t<512>(y, out, tw, cols, nframes, stream);
-        case 1024: return dop_launch_t<1024>(y, out, tw, cols, nframes, stream);
-        case 2048: return dop_launch_t<2048>(y, out, tw, cols, nframes, stream);
-        case 4096: return dop_launch_t<4096>(y, out, tw, cols, nframes, stream);
+        case 256: return dop_launch_t<256>(y, y_surface, out, tw, cols, nframes, stream);
+        case 512: return dop_launch_t<512>(y, y_surface, out, tw, cols, nframes, stream);
+        case 1024: return dop_launch_t<1024>(y, y_surface, out, tw, cols, nframes, stream);
+        case 2048: return dop_launch_t<2048>(y, y_surface, out, tw, cols, nframes, stream);
+        case 4096: return dop_launch_t<4096>(y, y_surface, out, tw, cols, nframes, stream);
     }
     prc_set_error("dop_launch: unsupported freq_bins %d", F);
     return PRC_EUNSUPPORTED;

@@ -112,7 +112,6 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
     const int hi = n_hi64 > N - 1 ? N - 1 : (int)n_hi64;
     const unsigned vo8 = (unsigned)lane * 8u, vo4 = (unsigned)lane * 4u;
     auto clampu = [](int x) { return x < 0 ? 0u : (unsigned)x; };
-    float2* __restrict__ yrow = a.s.y + ((int64_t)b * a.s.freq_bins + j) * (R + 1);
     const float sc = 1.0f / 1024.0f;
 
     for (int lb0 = 0; lb0 < a.nlagblk; lb0 += NLB) {
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_ker
             for (int r = 0; r < 16; ++r) {
                 const int within = 64 * r + lane;
                 const int lag = L0 + within;
-                if (within < LB && lag <= R) yrow[R - lag] = make_float2(acc[l][r].x * sc, -acc[l][r].y * sc);
+                if (within < LB && lag <= R) a.s.y[caf_y_off(a.s, b, j, R - lag)] = make_float2(acc[l][r].x * sc, -acc[l][r].y * sc);
             }
         }
     }

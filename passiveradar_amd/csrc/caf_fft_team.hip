@@ -106,7 +106,6 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
         int tail = len % B;
         if (tail > CAFT_TAIL_MAX || len < B) tail = 0;
         const int hi_f = hi - tail;                            // last sample that goes through the transforms
-        float2* __restrict__ yrow = a.s.y + ((int64_t)b * a.s.freq_bins + j) * (R + 1);
 
         for (int lb = 0; lb < a.nlagblk; ++lb) {
             float2 acc[16];
@@ -238,7 +237,7 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
             for (int r = 0; r < 16; ++r) {
                 const int within = 256 * r + t;
                 const int lag = L0 + within;
-                if (within < LB && lag <= R) yrow[R - lag] = make_float2(acc[r].x * sc, -acc[r].y * sc);
+                if (within < LB && lag <= R) a.s.y[caf_y_off(a.s, b, j, R - lag)] = make_float2(acc[r].x * sc, -acc[r].y * sc);
             }
         }
     }

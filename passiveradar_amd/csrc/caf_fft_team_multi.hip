@@ -151,8 +151,7 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_MULTI_WAVES) void caf_fft_team_mul
             const int L0 = lb * LB;
             for (int i = 0; i < a.nref; ++i) {
                 const float2* __restrict__ ref = a.refs[i] + (int64_t)b * a.s.frame_stride;
-                float2* __restrict__ yrow = a.s.y + (int64_t)i * a.y_ref_stride +
-                                            ((int64_t)b * a.s.freq_bins + j) * (R + 1);
+                float2* __restrict__ ybase = a.s.y + (int64_t)i * a.y_ref_stride;     // illuminator i's surfaces
                 const bool more = i + 1 < a.nref;
                 const float2* __restrict__ refn = a.refs[more ? i + 1 : i] + (int64_t)b * a.s.frame_stride;
                 float2 u[16], acc[16];
@@ -187,7 +186,7 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_MULTI_WAVES) void caf_fft_team_mul
                 for (int r = 0; r < 16; ++r) {
                     const int within = 256 * r + t;
                     const int lag = L0 + within;
-                    if (within < LB && lag <= R) yrow[R - lag] = make_float2(acc[r].x * sc, -acc[r].y * sc);
+                    if (within < LB && lag <= R) ybase[caf_y_off(a.s, b, j, R - lag)] = make_float2(acc[r].x * sc, -acc[r].y * sc);
                 }
             }
         }

@@ -1,5 +1,9 @@
 // Doppler stage of fast_xambg as ONE kernel: FFT over slow time + fftshift (range_doppler_processing.py:89)
-// straight from the segment kernels' row-major slow-time buffer y[frame][j][k] to out[frame][f'][k].
+// straight from the segment kernels' slow-time buffer to out[frame][f'][k].  The buffer is TILE-MAJOR (round 4),
+// y[frame][k / KT][j][k % KT]: a workgroup's tile is one contiguous block of F KT samples, so every wavefront load is
+// 512 contiguous bytes; with plain rows y[frame][j][k] (rounds 1-3) it was eight 64-byte pieces a row pitch apart, most
+// of them straddling two 128-byte lines (cols is odd), and the 2048-bin kernel ran at 3.1 TB/s against 5.1 TB/s when
+// both sides are contiguous (tools/caf_bench.py --shape dop2048x8).  The stores keep the (F, R+1) layout of the API.
 //
 // Round 1/2 ran transpose -> rocFFT (contiguous batch) -> shift+transpose: seven passes over the surface for two
 // of algorithmic traffic.  Here a workgroup owns a tile of KT adjacent range columns and all F slow-time rows:
@@ -241,5 +245,7 @@ PRC_HD int dop_out_row_reg(int m) {
 // host side (caf_doppler.hip): W_F^m table, does the column kernel take this size, launch
 void dop_make_table(float2* host_tab, int F);
 bool dop_supported(int freq_bins, int cols);
-int dop_launch(const float2* y, float2* out, const float2* tw, int freq_bins, int cols, int nframes,
+int dop_tile_cols(int freq_bins);           // KT: columns per tile (the slow-time buffer is laid out in such tiles)
+// y: tile-major slow-time buffer, y[frame][tile][j][KT], y_surface elements per frame; out: [frame][f'][cols]
+int dop_launch(const float2* y, int64_t y_surface, float2* out, const float2* tw, int freq_bins, int cols, int nframes,
                hipStream_t stream);

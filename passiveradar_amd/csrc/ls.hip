@@ -788,22 +788,35 @@ __global__ __launch_bounds__(LS_THREADS) void fir_subtract_kernel(FirArgs a) {
         Rt[i] = v;
     }
     __syncthreads();
-    float2 acc[FIR_OPT];
+    // Double-precision accumulation.  A float32 accumulator over a long filter (1034 taps at config 3) loses 4e-6 of
+    // the INPUT level, which is 1e-3 of the hundred times smaller cleaned output (the reference's own complex64 matrix
+    // product has that error; the FFT kernels do not); float32 blocks of 16 summed in double still left 2.5e-4.  This is the
+    // fallback kernel (method = 1, or more taps than the FFT kernels carry): the products of the float32 taps and samples
+    // are formed and summed in double (fp64 FMA, half the fp32 rate) and the 1e-4 bar holds on the output (round 4).
+    double2 dacc[FIR_OPT];
 #pragma unroll
-    for (int o = 0; o < FIR_OPT; ++o) acc[o] = make_float2(0.f, 0.f);
+    for (int o = 0; o < FIR_OPT; ++o) dacc[o] = make_double2(0.0, 0.0);
     const float2* Rl = Rt + tid + halo;
 #pragma unroll 2
     for (int k = 0; k < a.T; ++k) {
-        const float2 wk = W[k];
+        const float2 wf = W[k];
+        const double wx = (double)wf.x, wy = (double)wf.y;
 #pragma unroll
-        for (int o = 0; o < FIR_OPT; ++o) cmac(acc[o], wk, Rl[o * LS_THREADS - k]);
+        for (int o = 0; o < FIR_OPT; ++o) {
+            const float2 rf = Rl[o * LS_THREADS - k];
+            const double rx = (double)rf.x, ry = (double)rf.y;
+            dacc[o].x = fma(wx, rx, dacc[o].x);
+            dacc[o].x = fma(-wy, ry, dacc[o].x);
+            dacc[o].y = fma(wx, ry, dacc[o].y);
+            dacc[o].y = fma(wy, rx, dacc[o].y);
+        }
     }
 #pragma unroll
     for (int o = 0; o < FIR_OPT; ++o) {
         const int64_t n = n0 + tid + o * LS_THREADS;
         if (n < a.n) {
             const float2 s = srv[n];
-            a.out[(int64_t)b * a.out_stride + n] = make_float2(s.x - acc[o].x, s.y - acc[o].y);
+            a.out[(int64_t)b * a.out_stride + n] = make_float2((float)((double)s.x - dacc[o].x), (float)((double)s.y - dacc[o].y));
         }
     }
 }

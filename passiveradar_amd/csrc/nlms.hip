@@ -330,6 +330,11 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
         const double cost = rounds * (w == 4 ? 1.0 : (w == 8 ? 1.68 : 2.44));
         if (cost < best) { best = cost; nw = w; }
     }
+    // A/B runs (PRC_OPT_NLMS_WG_WAVES): a forced count; 16 = four wavefronts per SIMD, instantiated for the config-3
+    // filter (17 taps per lane, 118 VGPRs) -- its LDS window shrinks to 64 steps (16 streams share the CU's 160 KB)
+    const int forced = (int)prc_opt(PRC_OPT_NLMS_WG_WAVES);
+    if (forced == 16 && tpl == 17) nw = 16;
+    else if (forced >= 4 && forced <= maxw) nw = forced;
     const size_t lds_cu = 160 * 1024;
     int dev = 0;
     PRC_HIP(hipGetDevice(&dev));
@@ -385,6 +390,12 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
         hipLaunchKernelGGL((nlms_kernel<G, W>), dim3(grid), dim3(64 * nw), lds, (hipStream_t)stream, a); \
         PRC_LAUNCH_CHECK();                                                                     \
         return PRC_OK;                                                                          \
+    }
+    if (nw == 16) {
+        switch (tpl) {
+            PRC_NLMS_CASE(17, 16)
+            default: break;
+        }
     }
     switch (tpl) {
         PRC_NLMS_CASE(1, 12) PRC_NLMS_CASE(2, 12) PRC_NLMS_CASE(3, 12) PRC_NLMS_CASE(4, 12)

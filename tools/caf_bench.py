@@ -15,7 +15,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 SHAPES = {"cfg2": (2400000, 256, 512), "cfg3": (5000000, 1024, 1024), "cfg5": (1 << 23, 2048, 2048),
-          "cfg1": (262144, 256, 256)}
+          "cfg1": (262144, 256, 256),
+          # Doppler-stage probes: surfaces one tile wide, so that every row segment of a workgroup's tile is contiguous in
+          # memory on both sides (what a tile-major slow-time buffer would give the loads)
+          "dop2048x8": (131072, 7, 2048), "dop512x16": (32768, 15, 512)}
 
 
 def main():

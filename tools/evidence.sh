@@ -1,9 +1,9 @@
 #!/bin/bash
-# One round's evidence in one gpurun call (run from the repo root on the GPU box):   tools/evidence.sh r03
+# One round's evidence in one gpurun call (run from the repo root on the GPU box):   tools/evidence.sh r04
 # Everything lands under gpurun_out/ev_<tag>/ as raw rocprofv3 CSVs + the exact command of every run (cmd.txt), and
 # tools/evidence_summarize.py (run at the end, on the box) writes the summaries that get copied into profiles/.
 # rocprofv3 rules of this pool: counters (--pmc) in their own passes, never together with a trace domain.
-tag=${1:-r03}
+tag=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$PWD}
 E=$R/gpurun_out/ev_$tag
 mkdir -p $E
@@ -45,10 +45,19 @@ if [ "$EV_ONLY" = "cfg2" ]; then
 fi
 # 1. the bench lines of record (default with the CPU leg and the as-is figure; the other configs with their CPU legs)
 run bench_default $B --cpu-asis
-run bench_default_allcores $B --steps 5 --cpu-workers all
+[ "$EV_ALLCORES" = "1" ] && run bench_default_allcores $B --steps 5 --cpu-workers all     # 256 workers: ~8 minutes of box time
 run bench_cfg3 $B --workload cfg3
 run bench_cfg4 $B --workload cfg4 --no-cpu
 run bench_cfg5 $B --workload cfg5
+run bench_prconfig $B --workload prconfig --steps 3
+# one rank's share of the 600 s stream at 8 ranks: first, a middle and the (ragged) last shard
+for k in 0 3 7; do run bench_cfg4_shard${k}of8 $B --workload cfg4 --no-cpu --shard-of $k/8; done
+# shortFilt=False at config 2: the FFT segment kernel's long-FIR form against the time-domain kernel
+run caf_longfir_fft python3 $R/tools/caf_bench.py --shape cfg2 --frames 16 --long-fir --caf-method 2 --reps 3
+run caf_longfir_direct python3 $R/tools/caf_bench.py --shape cfg2 --frames 16 --long-fir --caf-method 1 --reps 3
+# multi-illuminator modes on one box
+for m in turns shared pairs; do run caf_multi_cfg5_$m python3 $R/tools/caf_bench.py --shape cfg5 --frames 16 --nref 4 --multi $m; done
+for m in turns shared; do run caf_multi_cfg3_$m python3 $R/tools/caf_bench.py --shape cfg3 --frames 32 --nref 4 --multi $m; done
 # 2. kernel traces: the default pipeline (overlapped streams) and the same kernels back to back on one stream
 trace trace_cfg2 --no-cpu --frames 1024 --steps 5 --warmup 1
 trace trace_cfg2_serial --no-cpu --frames 1024 --steps 5 --warmup 1 --no-overlap

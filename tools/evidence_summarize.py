@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E = os.path.join(REPO, "gpurun_out", f"ev_{tag}")
 S = os.path.join(E, "summary")
@@ -33,7 +33,9 @@ def cmd(name):
 
 
 # ---- bench lines ---------------------------------------------------------------------------------------------------
-for name in ("bench_default", "bench_default_allcores", "bench_cfg3", "bench_cfg4", "bench_cfg5"):
+for name in ("bench_default", "bench_default_allcores", "bench_cfg3", "bench_cfg4", "bench_cfg5", "bench_prconfig",
+             "bench_cfg4_shard0of8", "bench_cfg4_shard3of8", "bench_cfg4_shard7of8", "caf_longfir_fft", "caf_longfir_direct",
+             "caf_multi_cfg5_turns", "caf_multi_cfg5_shared", "caf_multi_cfg5_pairs", "caf_multi_cfg3_turns", "caf_multi_cfg3_shared"):
     d = load_line(name)
     if d:
         json.dump(d, open(os.path.join(S, f"{tag}_{name}.json"), "w"), indent=1)
