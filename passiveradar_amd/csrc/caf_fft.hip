@@ -52,7 +52,13 @@ int fftw_device_tables(const float2** out) {
     return PRC_OK;
 }
 
+// wavefronts per workgroup (they share the twiddle tables in LDS) and, for the single-lag-block form, wavefronts per SIMD
+#ifndef CAFF_WAVES
 #define CAFF_WAVES 4
+#endif
+#ifndef CAFF_OCC
+#define CAFF_OCC 3
+#endif
 
 struct CafFftArgs {
     CafSegArgs s;
@@ -74,12 +80,12 @@ struct CafFftArgs {
 // instead of w[n] -- segments of 10 q + 1 samples, ten-fold overlapped, one more 4-byte stream (the reversed taps) next to
 // the window.  Single-lag-block form only (up to 769 lags); wider spans stay on the time-domain kernel.
 template <bool HAS_WIN, int NLB, bool HAS_TAPS = false>
-__global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? 3 : 2) void caf_fft_kernel(CafFftArgs a) {
+__global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? CAFF_OCC : 2) void caf_fft_kernel(CafFftArgs a) {
     static_assert(!HAS_TAPS || NLB == 1, "the long-FIR form is the single-lag-block kernel");
     constexpr bool PREFETCH = NLB != 1;
     // single-lag-block form: the surveillance loads of a piece are issued BEFORE the reference transform and fly under it
-#ifdef CAFF_LATE_V
-    constexpr bool EARLY_V = false;
+#if defined(CAFF_LATE_V) || CAFF_OCC > 3
+    constexpr bool EARLY_V = false;                     // (four wavefronts per SIMD: 128 VGPRs, nothing in flight under a transform)
 #else
     constexpr bool EARLY_V = NLB == 1 && !HAS_TAPS;     // (a third 4-byte stream in flight: the registers are taken)
 #endif
@@ -312,26 +318,30 @@ int caf_launch_fft(const CafSegArgs& s, int nframes, hipStream_t stream) {
     if (rc) return rc;
     dim3 grid((unsigned)((s.freq_bins + CAFF_WAVES - 1) / CAFF_WAVES), (unsigned)nframes);
     const size_t lds = sizeof(float2) * (FFTW_TABLE + CAFF_WAVES * FFTW_TILE);
+    const dim3 block(64 * CAFF_WAVES);
+#define CAFF_LAUNCH(...)                                                                                       \
+    do {                                                                                                       \
+        if (lds > 64 * 1024) {                                                                                 \
+            rc = prc_lds_optin(reinterpret_cast<const void*>(&caf_fft_kernel<__VA_ARGS__>), (int)lds);         \
+            if (rc) return rc;                                                                                 \
+        }                                                                                                      \
+        hipLaunchKernelGGL((caf_fft_kernel<__VA_ARGS__>), grid, block, lds, stream, a);                        \
+    } while (0)
     if (s.taps_rev) {
         PRC_REQUIRE(s.range_bins + 1 <= 769, PRC_EUNSUPPORTED, "caf_launch_fft: the long-FIR form takes up to 769 lags");
         a.nlagblk = 1;
         a.lagblk = s.range_bins + 1;
         a.piece = FFTW_P + 1 - a.lagblk;
-        if (s.window)
-            hipLaunchKernelGGL((caf_fft_kernel<true, 1, true>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
-        else
-            hipLaunchKernelGGL((caf_fft_kernel<false, 1, true>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+        if (s.window) CAFF_LAUNCH(true, 1, true);
+        else CAFF_LAUNCH(false, 1, true);
     } else if (a.nlagblk == 1) {
-        if (s.window)
-            hipLaunchKernelGGL((caf_fft_kernel<true, 1>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
-        else
-            hipLaunchKernelGGL((caf_fft_kernel<false, 1>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+        if (s.window) CAFF_LAUNCH(true, 1);
+        else CAFF_LAUNCH(false, 1);
     } else {
-        if (s.window)
-            hipLaunchKernelGGL((caf_fft_kernel<true, 2>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
-        else
-            hipLaunchKernelGGL((caf_fft_kernel<false, 2>), grid, dim3(64 * CAFF_WAVES), lds, stream, a);
+        if (s.window) CAFF_LAUNCH(true, 2);
+        else CAFF_LAUNCH(false, 2);
     }
+#undef CAFF_LAUNCH
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }

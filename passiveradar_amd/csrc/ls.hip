@@ -66,11 +66,16 @@ __global__ __launch_bounds__(LS_THREADS) void corr_partial_kernel(CorrArgs a) {
     if (m_end > a.n) m_end = a.n;
 
     for (int L0 = 0; L0 < a.nlags; L0 += 64 * NLG) {
+        // float32 fused multiply-adds in runs of 32 samples, the runs summed in double: a single float32 accumulator over
+        // the 1024 samples a wavefront sums per partial left 8e-7 in the taps, which at 1034 taps is 2e-4 of a cleaned
+        // output a hundred times below its input (round 4; the FFT kernels sum per 1024- or 4096-point transform and the
+        // solve kernels add the partials in double)
         float2 acc[NS][NLG];
+        double2 dacc[NS][NLG];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int g = 0; g < NLG; ++g) acc[s][g] = make_float2(0.f, 0.f);
+            for (int g = 0; g < NLG; ++g) { acc[s][g] = make_float2(0.f, 0.f); dacc[s][g] = make_double2(0.0, 0.0); }
 
         for (int64_t t0 = m_begin; t0 < m_end; t0 += LSC_TILE) {
             const int64_t rem = m_end - t0;
@@ -100,21 +105,33 @@ __global__ __launch_bounds__(LS_THREADS) void corr_partial_kernel(CorrArgs a) {
             if (i1 > cnt) i1 = cnt;
             const float2* S1l = S1 + lane;
             const float2* S2l = S2 + lane;
+            for (int ia = i0; ia < i1; ia += 32) {
+                const int ib = ia + 32 < i1 ? ia + 32 : i1;
 #pragma unroll 2
-            for (int i = i0; i < i1; ++i) {
-                const float2 p = P[i];
+                for (int i = ia; i < ib; ++i) {
+                    const float2 p = P[i];
 #pragma unroll
-                for (int g = 0; g < NLG; ++g) {
-                    cmac_conj(acc[0][g], p, S1l[i + 64 * g]);
-                    if (DUAL) cmac_conj(acc[NS - 1][g], p, S2l[i + 64 * g]);
+                    for (int g = 0; g < NLG; ++g) {
+                        cmac_conj(acc[0][g], p, S1l[i + 64 * g]);
+                        if (DUAL) cmac_conj(acc[NS - 1][g], p, S2l[i + 64 * g]);
+                    }
                 }
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int g = 0; g < NLG; ++g) {
+                        dacc[s][g].x += (double)acc[s][g].x;
+                        dacc[s][g].y += (double)acc[s][g].y;
+                        acc[s][g] = make_float2(0.f, 0.f);
+                    }
             }
             __syncthreads();
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int g = 0; g < NLG; ++g) red[((wave * NS + s) * NLG + g) * 64 + lane] = acc[s][g];
+            for (int g = 0; g < NLG; ++g)
+                red[((wave * NS + s) * NLG + g) * 64 + lane] = make_float2((float)dacc[s][g].x, (float)dacc[s][g].y);
         __syncthreads();
         for (int t = tid; t < NS * NLG * 64; t += LS_THREADS) {
             float2 v = red[t];

@@ -371,8 +371,10 @@ def test_bench_default_workload_maps_against_an_independent_pass(tmp_path):
     maps = be.run(ref_pad, srv_pad, nfr, 0, nfr)
     torch.cuda.synchronize()
     got = d["ill0_frames"]
+    # not bit-equal by construction: a plan of 258 blocks cuts a chunk into 9 teams of ~35 pieces, a plan of 7 blocks into
+    # 78 teams of 4, so the float32 partial sums of the correlations group differently (measured: 1.0e-6 on frame 300)
     for j, fi in enumerate(d["frame_index"]):
-        assert rel_err(got[j], maps[int(fi)].cpu().numpy()) < 1e-6, int(fi)
+        assert rel_err(got[j], maps[int(fi)].cpu().numpy()) < 5e-6, int(fi)
     assert rel_err(d["ill0_sums"], maps.sum(dim=(1, 2)).cpu().numpy()) < 1e-5
 
 
