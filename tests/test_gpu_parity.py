@@ -902,3 +902,30 @@ def test_caf_multi_auto_choice():
         assert engine.CafPlan(1 << 23, 2048, 2048, 2).multi == _lib.CAF_MULTI_SHARED
     finally:
         _lib.set_option(_lib.OPT_CAF_MULTI_MODE, old)
+
+
+@pytest.mark.parametrize("L", [256, 700])
+def test_ls_plan_without_a_spectrum_cache(L):
+    """when the spectrum cache cannot be had (allocation failure, or PRC_OPT_LS_CACHE_LIMIT_MB as here) a plan
+    that asked for the 4096-point chain falls back BEFORE it sizes its workspaces -- to the 1024-point chain, which
+    recomputes the block spectra per bin when its own cache is refused too -- with the same results as the cached chain"""
+    import torch
+    from passiveradar_amd import _lib, engine
+    n, fs, bins = 131072, 2.4e6, (0.0, 1.0, -1.0)
+    ref, srv = scene.make_scene(n, fs, min(L, 200), 4242 + L)
+    a, s = torch.from_numpy(ref).cuda(), torch.from_numpy(srv).cuda()
+    outs = []
+    for limit in (0, 1):                                   # 0: no limit; 1 MiB: no cache of this size fits
+        old = _lib.set_option(_lib.OPT_LS_CACHE_LIMIT_MB, limit)
+        try:
+            plan = engine.LsPlan(n, L, 10, False, 2, 4)
+        finally:
+            _lib.set_option(_lib.OPT_LS_CACHE_LIMIT_MB, old)
+        out = torch.empty_like(s)
+        plan.execute(a, s, out, 1, n, n, fs, bins, 0.0, None, _lib.torch_stream_ptr())
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+        plan.close()
+    exp = O.LS_Filter_Multiple(ref, srv, L, fs, list(bins))
+    assert rel_err(outs[0], exp) < TOL and rel_err(outs[1], exp) < TOL
+    assert rel_err(outs[1], outs[0]) < 1e-5
