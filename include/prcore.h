@@ -172,9 +172,11 @@ typedef struct prc_ls_desc {
                               <= 769 taps, n >= 8192: fewer cache bytes per sample; else as 3).  The FFT
                               kernels take up to 769 taps on 1024-point transforms (one wavefront
                               each) and up to 3073 taps on 4096-point transforms (four wavefronts).
-                              LIMIT: filter_len + peek <= 3413 taps for every method (the Levinson
-                              recursion keeps three T-vectors of complex128 in the 160 KB of LDS);
-                              beyond that prc_ls_plan_create returns PRC_EUNSUPPORTED -- the reference
+                              LIMIT: filter_len + peek <= 5120 taps for every method (the Levinson
+                              recursion keeps the two complex128 T-vectors it rewrites in the 160 KB of LDS;
+                              up to 3413 taps the autocorrelation sits there too, beyond it is read from a
+                              global workspace; above 3073 taps correlations and FIR run on the time-domain
+                              kernels); beyond that prc_ls_plan_create returns PRC_EUNSUPPORTED -- the reference
                               (clutter_removal.py:109-160) accepts any length                         */
 } prc_ls_desc;
 

@@ -215,16 +215,21 @@ __device__ __forceinline__ double wave_allsum_d(double v) {
 // a[m-j] into a[j] + k conj(a[m-j]) and a[m-j] + k conj(a[j]) together, one lane per pair, so no second predictor
 // buffer exists and a lane's loop is half as long; the right-hand side b is read from HBM one element per step
 // (round 2 held five arrays in LDS and stopped at 2047 taps).
+// C_GLOBAL (3414 .. 5120 taps, round 4): the autocorrelation c[] -- written once by the prologue, read-only in the
+// recursion -- lives in a global workspace (c_ws, [block][T]) instead of LDS, which then holds only the two vectors the
+// recursion rewrites (32 T bytes); its reads are ordinary cached loads behind one fence.
+template <bool C_GLOBAL>
 __global__ __launch_bounds__(64) void levinson_wave_kernel(const float2* __restrict__ partial,
                                                            int nblk, int T, double reg,
                                                            double2* __restrict__ taps_out,
-                                                           double2* __restrict__ rhs_ws) {
+                                                           double2* __restrict__ rhs_ws, double2* __restrict__ c_ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double2* c = reinterpret_cast<double2*>(smem_raw);
-    double2* a = c + T;
+    double2* lds0 = reinterpret_cast<double2*>(smem_raw);
+    const int b = blockIdx.x;
+    double2* c = C_GLOBAL ? c_ws + (int64_t)b * T : lds0;
+    double2* a = C_GLOBAL ? lds0 : lds0 + T;
     double2* w = a + T;
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;
     const float2* part = partial + (int64_t)b * nblk * 2 * T;
     double2* __restrict__ bb = rhs_ws + (int64_t)b * T;
     for (int k = lane; k < T; k += 64) {
@@ -242,6 +247,7 @@ __global__ __launch_bounds__(64) void levinson_wave_kernel(const float2* __restr
         a[k] = make_double2(k == 0 ? 1.0 : 0.0, 0.0);
         w[k] = make_double2(0.0, 0.0);
     }
+    if (C_GLOBAL) __threadfence();                // c[] went to memory: visible to the other lanes' loads below
     __syncthreads();                              // one wavefront: orders the LDS and the global writes above
     double err = c[0].x;
     if (lane == 0) w[0] = zdiv(bb[0], c[0]);
@@ -851,6 +857,7 @@ struct prc_ls_plan {
     float2* d_partial = nullptr;
     double2* d_taps = nullptr;
     double2* d_rhs = nullptr;      // right-hand sides of the per-bin Levinson solve, [block][T] (one element read per step)
+    double2* d_cws = nullptr;      // autocorrelations of that solve beyond 3413 taps, [block][T] (levinson_wave_kernel<true>)
     float2* d_tmp[2] = {nullptr, nullptr};
     // shared-inverse path (non-circular FFT chain): c_0, S_e, dense T_0^{-1} per block
     double2* d_c0 = nullptr;
@@ -876,6 +883,7 @@ extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
     if (p->d_partial) (void)hipFree(p->d_partial);
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_rhs) (void)hipFree(p->d_rhs);
+    if (p->d_cws) (void)hipFree(p->d_cws);
     if (p->d_tmp[0]) (void)hipFree(p->d_tmp[0]);
     if (p->d_tmp[1]) (void)hipFree(p->d_tmp[1]);
     if (p->d_c0) (void)hipFree(p->d_c0);
@@ -890,7 +898,9 @@ extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
     return PRC_OK;
 }
 
-static size_t levinson_lds(int T) { return sizeof(double2) * ((size_t)3 * T); }
+// c, a, w in LDS up to 3413 taps; beyond that c moves to a global workspace (levinson_wave_kernel<true>) and a, w stay: 5120
+static bool levinson_c_global(int T) { return sizeof(double2) * ((size_t)3 * T) > 160 * 1024; }
+static size_t levinson_lds(int T) { return sizeof(double2) * ((size_t)(levinson_c_global(T) ? 2 : 3) * T); }
 static size_t fir_lds(int T) { return sizeof(float2) * ((size_t)T + FIR_SPAN + T - 1); }
 
 extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
@@ -902,7 +912,7 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     PRC_REQUIRE(T < d->n, PRC_EINVAL, "prc_ls_plan_create: filter_len+peek (%d) >= n (%lld)", T,
                 (long long)d->n);
     PRC_REQUIRE(levinson_lds(T) <= 160 * 1024, PRC_EUNSUPPORTED,
-                "prc_ls_plan_create: %d taps exceed the LDS-resident Levinson solver (max 3413)", T);
+                "prc_ls_plan_create: %d taps exceed the Levinson solver (two complex128 T-vectors in the 160 KB of LDS: max 5120)", T);
     prc_ls_plan* p = new prc_ls_plan();
     p->desc = *d;
     p->T = T;
@@ -992,8 +1002,12 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
             e = hipFuncSetAttribute((const void*)ls_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)levinson_wave_kernel,
+        e = hipFuncSetAttribute((const void*)levinson_wave_kernel<false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)levinson_wave_kernel<true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && levinson_c_global(T)) e = hipMalloc(&p->d_cws, sizeof(double2) * (size_t)d->max_blocks * T);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)fir_subtract_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1213,8 +1227,12 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
             }
             if (rc) return rc;
             if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 1], stream));
-            hipLaunchKernelGGL(levinson_wave_kernel, dim3(nblocks), dim3(64), levinson_lds(T), stream,
-                               p->d_partial, p->nblk, T, reg, p->d_taps, p->d_rhs);
+            if (levinson_c_global(T))
+                hipLaunchKernelGGL(levinson_wave_kernel<true>, dim3(nblocks), dim3(64), levinson_lds(T), stream,
+                                   p->d_partial, p->nblk, T, reg, p->d_taps, p->d_rhs, p->d_cws);
+            else
+                hipLaunchKernelGGL(levinson_wave_kernel<false>, dim3(nblocks), dim3(64), levinson_lds(T), stream,
+                                   p->d_partial, p->nblk, T, reg, p->d_taps, p->d_rhs, (double2*)nullptr);
             PRC_LAUNCH_CHECK();
             if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
             if (p->method == 2) {

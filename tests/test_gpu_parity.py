@@ -605,7 +605,19 @@ def test_ls_up_to_the_3073_taps_of_the_team_kernels(L):
     out, taps = LS_Filter_Toeplitz(ref, srv, L, return_filter=True)
     assert rel_err(taps, etaps) < TIGHT and rel_err(out, exp) < TIGHT
     with pytest.raises(NotImplementedError):
-        LS_Filter_Toeplitz(ref, srv, 3500)                     # documented limit: 3413 taps
+        LS_Filter_Toeplitz(ref, srv, 5200)                     # documented limit: 5120 taps
+
+
+def test_ls_beyond_the_lds_resident_solver():
+    """3414 .. 5120 taps (round 4): the Levinson recursion keeps the two vectors it rewrites in LDS and reads the
+    autocorrelation from a global workspace; correlations and FIR on the time-domain kernels (double accumulation).  The
+    reference accepts any length (clutter_removal.py:109-160)"""
+    from passiveradar_amd.clutter_removal import LS_Filter_Toeplitz
+    n, L = 30000, 4000
+    ref, srv = scene.make_scene(n, 1.0e7, 200, 3000 + L)
+    exp, etaps = O.LS_Filter_Toeplitz(ref, srv, L, return_filter=True)
+    out, taps = LS_Filter_Toeplitz(ref, srv, L, return_filter=True)
+    assert rel_err(taps, etaps) < TIGHT and rel_err(out, exp) < TOL
 
 
 def test_ls_t1034_long_block_vs_oracle(ls_method):
