@@ -373,6 +373,46 @@ extern "C" int prc_caf_execute_multi(prc_caf_plan* p, const void* const* refs_ho
     const int per = p->multi == PRC_CAF_MULTI_SHARED ? nref : (p->multi == PRC_CAF_MULTI_PAIRS ? 2 : 1);
     const bool shared = per > 1 && p->method == PRC_CAF_FFT4096 && p->doppler == PRC_DOPPLER_COLUMN && nref > 1 &&
                         caf_team_multi_supported(p->desc.n, p->desc.range_bins, p->desc.freq_bins, p->ntaps, per);
+    if (!shared && nref > 1 && p->method == PRC_CAF_FFT4096 && p->doppler == PRC_DOPPLER_COLUMN) {
+        // "turns" in ONE launch per stage: the single-reference kernel with the illuminator as a third grid dimension, then the
+        // Doppler kernel over every channel's surfaces -- nothing shared, but no tail of nref small launches (config 5, 16
+        // frames: 10.7 rounds of workgroups per segment launch and 8.03 per Doppler launch, each rounded up, become 42.7 and 32.1)
+        int g = p->group / nref;
+        if (g < 1) g = 1;
+        for (int f0 = 0; f0 < nframes; f0 += g) {
+            const int nf = nframes - f0 < g ? nframes - f0 : g;
+            CafSegArgs a;
+            a.ref = nullptr;
+            a.srv = (const float2*)srv + (int64_t)f0 * frame_stride;
+            a.window = window;
+            a.taps = nullptr;
+            a.taps_rev = nullptr;
+            a.y = p->d_y2;
+            a.frame_stride = frame_stride;
+            a.n = p->desc.n;
+            a.n_valid = n_valid;
+            a.q = p->q;
+            a.ntaps = p->ntaps;
+            a.half = p->half;
+            a.range_bins = p->desc.range_bins;
+            a.freq_bins = p->desc.freq_bins;
+            a.y_layout = PRC_Y_JK;
+            a.y_kt = p->y_kt;
+            a.y_surface = p->y_surf;
+            const float2* refs[PRC_CAF_MAX_REFS];
+            float2* outs[PRC_CAF_MAX_REFS];
+            for (int i = 0; i < nref; ++i) {
+                refs[i] = (const float2*)refs_host[i] + (int64_t)f0 * frame_stride;
+                outs[i] = (float2*)outs_host[i] + (int64_t)f0 * se;
+            }
+            int rc = caf_launch_fft_team_refs(a, refs, nref, (int64_t)nf * p->y_surf, nf, st);
+            if (rc) return rc;
+            rc = dop_launch_multi(p->d_y2, p->y_surf, (int64_t)nf * p->y_surf, outs, nref, p->d_dop_tw, p->desc.freq_bins,
+                                  p->desc.range_bins + 1, nf, st);
+            if (rc) return rc;
+        }
+        return PRC_OK;
+    }
     if (!shared) {
         // one pass per illuminator (any method): same results, nothing shared
         for (int i = 0; i < nref; ++i) {
@@ -418,11 +458,11 @@ extern "C" int prc_caf_execute_multi(prc_caf_plan* p, const void* const* refs_ho
             int rc = caf_launch_fft_team_multi(a, refs, k, (int64_t)nf * p->y_surf, nf, st);
             if (rc) return rc;
         }
-        for (int i = 0; i < nref; ++i) {
-            int rc = dop_launch(p->d_y2 + (int64_t)i * nf * p->y_surf, p->y_surf, (float2*)outs_host[i] + (int64_t)f0 * se,
-                                p->d_dop_tw, p->desc.freq_bins, p->desc.range_bins + 1, nf, st);
-            if (rc) return rc;
-        }
+        float2* outs[PRC_CAF_MAX_REFS];
+        for (int i = 0; i < nref; ++i) outs[i] = (float2*)outs_host[i] + (int64_t)f0 * se;
+        int rc = dop_launch_multi(p->d_y2, p->y_surf, (int64_t)nf * p->y_surf, outs, nref, p->d_dop_tw, p->desc.freq_bins,
+                                  p->desc.range_bins + 1, nf, st);
+        if (rc) return rc;
     }
     return PRC_OK;
 }

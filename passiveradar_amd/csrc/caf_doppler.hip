@@ -10,9 +10,15 @@
 // Workgroups reach the XCDs round-robin in launch order and every XCD has its own L2: workgroup b takes tile
 // (b % 8) * per_xcd + b / 8, so an XCD works through one contiguous run of tiles -- neighbouring tiles split 128-byte
 // lines of y and out between them.
+struct DopOuts {                       // per-channel output pointers of a multi-channel launch (one entry for a plain launch)
+    float2* out[8];
+    int64_t y_ch_stride;               // elements between the channels' surface blocks in y
+    int per_ch;                        // tiles * frames of one channel
+};
+
 template <int F>
 __global__ __launch_bounds__(DopCfg<F>::THREADS) void doppler_col_kernel(const float2* __restrict__ y, int64_t y_surface,
-                                                                         float2* __restrict__ out,
+                                                                         DopOuts outs,
                                                                          const float2* __restrict__ tw, int cols,
                                                                          int tiles, int total) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dop_smem[];
@@ -21,7 +27,10 @@ __global__ __launch_bounds__(DopCfg<F>::THREADS) void doppler_col_kernel(const f
     const int per_xcd = (total + 7) >> 3;
     const int work = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
     if (work >= total) return;                                  // uniform
-    const int frame = work / tiles, tile = work - frame * tiles;
+    const int ch = work / outs.per_ch, wch = work - ch * outs.per_ch;
+    const int frame = wch / tiles, tile = wch - frame * tiles;
+    float2* __restrict__ out = outs.out[ch];
+    y += (int64_t)ch * outs.y_ch_stride;
     const int c = threadIdx.x % KT, p = threadIdx.x / KT;
     const int k = tile * KT + c;
     // Raw buffer accesses: bases are uniform, a thread's part of the offset is ONE 32-bit VGPR per side, and the register's
@@ -112,7 +121,8 @@ int dop_tile_cols(int F) {
 }
 
 template <int F>
-static int dop_launch_t(const float2* y, int64_t y_surface, float2* out, const float2* tw, int cols, int nframes, hipStream_t stream) {
+static int dop_launch_t(const float2* y, int64_t y_surface, int64_t y_ch_stride, float2* const* outs, int nch, const float2* tw,
+                        int cols, int nframes, hipStream_t stream) {
     constexpr int KT = DopCfg<F>::KT;
     const size_t lds = DopCfg<F>::LDS_BYTES;
     static bool attr_done[16] = {false};
@@ -123,22 +133,35 @@ static int dop_launch_t(const float2* y, int64_t y_surface, float2* out, const f
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev >= 0 && dev < 16) attr_done[dev] = true;
     }
-    const int tiles = (cols + KT - 1) / KT, total = tiles * nframes;
+    const int tiles = (cols + KT - 1) / KT;
+    DopOuts o;
+    for (int i = 0; i < 8; ++i) o.out[i] = i < nch ? outs[i] : nullptr;
+    o.y_ch_stride = y_ch_stride;
+    o.per_ch = tiles * nframes;
+    const int total = o.per_ch * nch;
     dim3 grid((unsigned)(((total + 7) / 8) * 8));
-    hipLaunchKernelGGL((doppler_col_kernel<F>), grid, dim3(DopCfg<F>::THREADS), lds, stream, y, y_surface, out, tw, cols,
+    hipLaunchKernelGGL((doppler_col_kernel<F>), grid, dim3(DopCfg<F>::THREADS), lds, stream, y, y_surface, o, tw, cols,
                        tiles, total);
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }
 
-int dop_launch(const float2* y, int64_t y_surface, float2* out, const float2* tw, int F, int cols, int nframes, hipStream_t stream) {
+// nch channels (illuminators) in one launch: channel i's nframes surfaces start at y + i * y_ch_stride and go to outs[i]
+int dop_launch_multi(const float2* y, int64_t y_surface, int64_t y_ch_stride, float2* const* outs, int nch, const float2* tw,
+                     int F, int cols, int nframes, hipStream_t stream) {
+    PRC_REQUIRE(nch >= 1 && nch <= 8, PRC_EINVAL, "dop_launch_multi: %d channels", nch);
     switch (F) {
-        case 256: return dop_launch_t<256>(y, y_surface, out, tw, cols, nframes, stream);
-        case 512: return dop_launch_t<512>(y, y_surface, out, tw, cols, nframes, stream);
-        case 1024: return dop_launch_t<1024>(y, y_surface, out, tw, cols, nframes, stream);
-        case 2048: return dop_launch_t<2048>(y, y_surface, out, tw, cols, nframes, stream);
-        case 4096: return dop_launch_t<4096>(y, y_surface, out, tw, cols, nframes, stream);
+        case 256: return dop_launch_t<256>(y, y_surface, y_ch_stride, outs, nch, tw, cols, nframes, stream);
+        case 512: return dop_launch_t<512>(y, y_surface, y_ch_stride, outs, nch, tw, cols, nframes, stream);
+        case 1024: return dop_launch_t<1024>(y, y_surface, y_ch_stride, outs, nch, tw, cols, nframes, stream);
+        case 2048: return dop_launch_t<2048>(y, y_surface, y_ch_stride, outs, nch, tw, cols, nframes, stream);
+        case 4096: return dop_launch_t<4096>(y, y_surface, y_ch_stride, outs, nch, tw, cols, nframes, stream);
     }
     prc_set_error("dop_launch: unsupported freq_bins %d", F);
     return PRC_EUNSUPPORTED;
+}
+
+int dop_launch(const float2* y, int64_t y_surface, float2* out, const float2* tw, int F, int cols, int nframes, hipStream_t stream) {
+    float2* one[1] = {out};
+    return dop_launch_multi(y, y_surface, 0, one, 1, tw, F, cols, nframes, stream);
 }

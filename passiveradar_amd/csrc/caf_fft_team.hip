@@ -70,6 +70,10 @@ struct CafTeamArgs {
     int32_t lagblk;     // lags per block (<= 3073)
     int32_t nlagblk;    // lag blocks covering 0..range_bins
     int32_t segs;       // consecutive slow-time samples per workgroup
+    // several reference channels in ONE launch (blockIdx.z; nothing shared between them -- "turns" without the tail of four
+    // small launches): channel z reads refs[z] and writes its surfaces y_ref_stride elements further on
+    const float2* refs[PRC_CAF_MAX_REFS];
+    int64_t y_ref_stride;
 };
 
 
@@ -83,9 +87,10 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
     const FtLane f = ft_setup(lds, a.gtab);
     const int t = f.t;
     const int b = blockIdx.y;
-    const float2* __restrict__ ref = a.s.ref + (int64_t)b * a.s.frame_stride;
+    const float2* __restrict__ ref = a.refs[blockIdx.z] + (int64_t)b * a.s.frame_stride;
     const float2* __restrict__ srv = a.s.srv + (int64_t)b * a.s.frame_stride;
     const float* __restrict__ win = a.s.window;
+    float2* __restrict__ ych = a.s.y + (int64_t)blockIdx.z * a.y_ref_stride;      // this channel's surfaces
     // frame-relative 32-bit arithmetic (n < 2^31); everything but t is workgroup-uniform
     const int N = (int)a.s.n, NV = (int)a.s.n_valid;
     const int R = a.s.range_bins;
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
             for (int r = 0; r < 16; ++r) {
                 const int within = 256 * r + t;
                 const int lag = L0 + within;
-                if (within < LB && lag <= R) a.s.y[caf_y_off(a.s, b, j, R - lag)] = make_float2(acc[r].x * sc, -acc[r].y * sc);
+                if (within < LB && lag <= R) ych[caf_y_off(a.s, b, j, R - lag)] = make_float2(acc[r].x * sc, -acc[r].y * sc);
             }
         }
     }
@@ -271,17 +276,21 @@ bool caf_team_supported(int64_t n, int range_bins, int freq_bins, int boxcar) {
     return boxcar && range_bins >= 1 && n >= 8192 && n <= ((int64_t)1 << 28) && range_bins < n / 2;
 }
 
-int caf_launch_fft_team(const CafSegArgs& s, int nframes, hipStream_t stream) {
+int caf_launch_fft_team_refs(const CafSegArgs& s, const float2* const* refs, int nref, int64_t y_ref_stride, int nframes,
+                             hipStream_t stream) {
+    PRC_REQUIRE(nref >= 1 && nref <= PRC_CAF_MAX_REFS, PRC_EINVAL, "caf_launch_fft_team_refs: nref = %d", nref);
     CafTeamArgs a;
     a.s = s;
+    for (int i = 0; i < PRC_CAF_MAX_REFS; ++i) a.refs[i] = i < nref ? refs[i] : nullptr;
+    a.y_ref_stride = y_ref_stride;
     caf_team_blocking(s.ntaps, s.range_bins, &a.nlagblk, &a.lagblk);
     a.piece = FT_P + 1 - a.lagblk;
     int rc = ft_device_tables(&a.gtab);
     if (rc) return rc;
     // several segments per workgroup amortise the table set-up once there is plenty of work
-    const int64_t total = (int64_t)s.freq_bins * nframes;
+    const int64_t total = (int64_t)s.freq_bins * nframes * nref;
     a.segs = total >= 16384 ? 4 : (total >= 4096 ? 2 : 1);
-    dim3 grid((unsigned)((s.freq_bins + a.segs - 1) / a.segs), (unsigned)nframes);
+    dim3 grid((unsigned)((s.freq_bins + a.segs - 1) / a.segs), (unsigned)nframes, (unsigned)nref);
     const size_t lds = sizeof(float2) * FT_LDS_ELEMS;
     { int rc_ = prc_lds_optin(reinterpret_cast<const void*>(s.window ? &caf_fft_team_kernel<true> : &caf_fft_team_kernel<false>), (int)lds); if (rc_) return rc_; }
     if (s.window)
@@ -290,4 +299,9 @@ int caf_launch_fft_team(const CafSegArgs& s, int nframes, hipStream_t stream) {
         hipLaunchKernelGGL((caf_fft_team_kernel<false>), grid, dim3(FT_THREADS), lds, stream, a);
     PRC_LAUNCH_CHECK();
     return PRC_OK;
+}
+
+int caf_launch_fft_team(const CafSegArgs& s, int nframes, hipStream_t stream) {
+    const float2* one[1] = {s.ref};
+    return caf_launch_fft_team_refs(s, one, 1, 0, nframes, stream);
 }

@@ -6,6 +6,8 @@
 enum { PRC_Y_JK = 0,   // y[frame][j][k]   (k contiguous)  -> written row-wise by the FFT segment kernel
        PRC_Y_KJ = 1 }; // y[frame][k][j]   (j contiguous)  -> rocFFT batched plan
 
+#define PRC_CAF_MAX_REFS 8
+
 struct CafSegArgs {
     const float2* ref;
     const float2* srv;
@@ -52,12 +54,15 @@ bool caf_fft_supported(int64_t n, int range_bins, int freq_bins, int ntaps_is_bo
 // 4096-point team transforms (caf_fft_team.hip); the *_blocking functions return the cost of one segment in
 // transforms of their own size
 int caf_launch_fft_team(const CafSegArgs& a, int nframes, hipStream_t stream);
+// the same kernel for nref reference channels in one launch (blockIdx.z; nothing shared): channel i reads refs[i] and writes
+// its nframes surfaces at a.y + i * y_ref_stride
+int caf_launch_fft_team_refs(const CafSegArgs& a, const float2* const* refs, int nref, int64_t y_ref_stride, int nframes,
+                             hipStream_t stream);
 bool caf_team_supported(int64_t n, int range_bins, int freq_bins, int ntaps_is_boxcar);
 double caf_team_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out);
 double caf_fft_blocking(int64_t q1, int range_bins, int* nlb_out, int* lb_out);
 // nref reference channels against one surveillance channel in one launch (segments of <= 2 pieces): illuminator i's
 // surfaces go to y + i * y_ref_stride
-#define PRC_CAF_MAX_REFS 8
 int caf_launch_fft_team_multi(const CafSegArgs& a, const float2* const* refs, int nref, int64_t y_ref_stride,
                               int nframes, hipStream_t stream);
 bool caf_team_multi_supported(int64_t n, int range_bins, int freq_bins, int64_t q1, int nref);

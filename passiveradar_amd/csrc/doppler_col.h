@@ -249,3 +249,6 @@ int dop_tile_cols(int freq_bins);           // KT: columns per tile (the slow-ti
 // y: tile-major slow-time buffer, y[frame][tile][j][KT], y_surface elements per frame; out: [frame][f'][cols]
 int dop_launch(const float2* y, int64_t y_surface, float2* out, const float2* tw, int freq_bins, int cols, int nframes,
                hipStream_t stream);
+// nch channels in ONE launch: channel i's surfaces at y + i * y_ch_stride, its maps to outs[i]
+int dop_launch_multi(const float2* y, int64_t y_surface, int64_t y_ch_stride, float2* const* outs, int nch, const float2* tw,
+                     int freq_bins, int cols, int nframes, hipStream_t stream);
