@@ -74,7 +74,10 @@ typedef enum prc_option {
     PRC_OPT_NLMS_WG_WAVES = 6,    /* 0 (default): NLMS wavefronts (= independent streams) per workgroup / CU from the stream count
                                      and the measured step times; 4 / 8 / 12 / 16: forced (16 = four per SIMD exists for the
                                      config-3 filter length only; A/B runs)                                                */
-    PRC_OPT_COUNT_ = 7
+    PRC_OPT_CAF_XCD_CONTIG = 7,   /* workgroup order of the 4096-point segment kernel, read per launch (A/B runs): 0 (default) =
+                                     segments go round the XCDs in launch order, 1 = every XCD takes a contiguous run of them
+                                     (measured slower on MI355X)                                                            */
+    PRC_OPT_COUNT_ = 8
 } prc_option;
 int prc_set_option(int32_t option, int64_t value);     /* PRC_EINVAL for an unknown option or a value out of range */
 int prc_get_option(int32_t option, int64_t* value);

@@ -70,10 +70,12 @@ struct CafTeamArgs {
     int32_t lagblk;     // lags per block (<= 3073)
     int32_t nlagblk;    // lag blocks covering 0..range_bins
     int32_t segs;       // consecutive slow-time samples per workgroup
-    // several reference channels in ONE launch (blockIdx.z; nothing shared between them -- "turns" without the tail of four
+    // several reference channels in ONE launch (nothing shared between them but the L2 -- "turns" without the tail of four
     // small launches): channel z reads refs[z] and writes its surfaces y_ref_stride elements further on
     const float2* refs[PRC_CAF_MAX_REFS];
     int64_t y_ref_stride;
+    int32_t nref, chunks_x, nchunks;   // channels; workgroup chunks per frame; chunks_x * nframes
+    int32_t xcd_contig;                // 1: an XCD takes a contiguous run of chunks; 0: chunks go round the XCDs in launch order
 };
 
 
@@ -84,13 +86,26 @@ template <bool HAS_WIN>
 __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_kernel(CafTeamArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);
-    const FtLane f = ft_setup(lds, a.gtab);
-    const int t = f.t;
-    const int b = blockIdx.y;
-    const float2* __restrict__ ref = a.refs[blockIdx.z] + (int64_t)b * a.s.frame_stride;
+    // Workgroup -> work.  Workgroups reach the eight XCDs round-robin in launch order and every XCD has its own L2: workgroup
+    // L (XCD L & 7, slot L >> 3 there) takes channel (L >> 3) % nref of chunk 8 ((L >> 3) / nref) + (L & 7).  The channels of
+    // a multi-illuminator frame read the SAME surveillance windows and sit in consecutive slots of ONE XCD: one of them
+    // fetches a window from HBM, the others find it in that XCD's L2 (config 5, four channels: 222 -> 69 MB fetched per
+    // surface, 301 -> 281 us per frame).  Chunks themselves keep going round the XCDs: giving every XCD a contiguous run of
+    // segments instead (PRC_OPT_CAF_XCD_CONTIG = 1; neighbouring segments share half a window) measured 3-6 % SLOWER at
+    // one channel and at four, configs 3 and 5 alike (profiles/r04_ab_log.md, call 12) -- eight distant streams instead of
+    // one; it is the option's off position that ships.
+    const int per_xcd = (a.nchunks + 7) >> 3;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int ch = slot % a.nref, ci = slot / a.nref;
+    const int chunk = a.xcd_contig ? (int)(blockIdx.x & 7u) * per_xcd + ci : ci * 8 + (int)(blockIdx.x & 7u);
+    if (ci >= per_xcd || chunk >= a.nchunks) return;            // uniform, before any barrier
+    const int b = chunk / a.chunks_x, bx = chunk - b * a.chunks_x;
+    const float2* __restrict__ ref = a.refs[ch] + (int64_t)b * a.s.frame_stride;
     const float2* __restrict__ srv = a.s.srv + (int64_t)b * a.s.frame_stride;
     const float* __restrict__ win = a.s.window;
-    float2* __restrict__ ych = a.s.y + (int64_t)blockIdx.z * a.y_ref_stride;      // this channel's surfaces
+    float2* __restrict__ ych = a.s.y + (int64_t)ch * a.y_ref_stride;               // this channel's surfaces
+    const FtLane f = ft_setup(lds, a.gtab);
+    const int t = f.t;
     // frame-relative 32-bit arithmetic (n < 2^31); everything but t is workgroup-uniform
     const int N = (int)a.s.n, NV = (int)a.s.n_valid;
     const int R = a.s.range_bins;
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
     const float sc = 1.0f / (float)FT_P;
 
     for (int sg = 0; sg < a.segs; ++sg) {
-        const int64_t j = (int64_t)blockIdx.x * a.segs + sg;
+        const int64_t j = (int64_t)bx * a.segs + sg;
         if (j >= a.s.freq_bins) break;                         // uniform
         const int64_t n_hi64 = j * a.s.q + a.s.half;
         const int64_t n_lo64 = n_hi64 - (a.s.ntaps - 1);
@@ -290,7 +305,11 @@ int caf_launch_fft_team_refs(const CafSegArgs& s, const float2* const* refs, int
     // several segments per workgroup amortise the table set-up once there is plenty of work
     const int64_t total = (int64_t)s.freq_bins * nframes * nref;
     a.segs = total >= 16384 ? 4 : (total >= 4096 ? 2 : 1);
-    dim3 grid((unsigned)((s.freq_bins + a.segs - 1) / a.segs), (unsigned)nframes, (unsigned)nref);
+    a.nref = nref;
+    a.xcd_contig = (int)prc_opt(PRC_OPT_CAF_XCD_CONTIG);
+    a.chunks_x = (s.freq_bins + a.segs - 1) / a.segs;
+    a.nchunks = a.chunks_x * nframes;
+    dim3 grid((unsigned)(8 * ((a.nchunks + 7) / 8) * nref));
     const size_t lds = sizeof(float2) * FT_LDS_ELEMS;
     { int rc_ = prc_lds_optin(reinterpret_cast<const void*>(s.window ? &caf_fft_team_kernel<true> : &caf_fft_team_kernel<false>), (int)lds); if (rc_) return rc_; }
     if (s.window)
