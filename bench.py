@@ -554,8 +554,10 @@ def main():
             gathered[p] = ev_g
             return
         if multi and nframes:
-            # every illuminator of this rank against the shared surveillance channel in ONE call per sub-batch:
-            # prc_caf_execute_multi transforms the surveillance pieces once per segment for all of them
+            # every illuminator of this rank against the shared surveillance channel in ONE call per sub-batch
+            # (prc_caf_execute_multi; how the channels share work is the plan's prc_caf_desc.multi: at config 5 AUTO = one
+            # launch per stage for all channels, their workgroups co-located per XCD so that the surveillance windows are
+            # fetched once)
             be.frames_multi(refs, srv_pad, first, nframes, outs[p])
         else:
             for r_i, out in zip(refs, outs[p]):      # one fast_xambg pass per illuminator
@@ -768,6 +770,8 @@ def main():
             "hbm_algorithmic_GBps": per_frame_bytes * value / world / 1e9,
             "hbm_frac_of_peak": per_frame_bytes * value / world / 1e9 / HBM_PEAK_GBS,
             "hbm_frac_of_copy_ceiling": per_frame_bytes * value / world / 1e9 / 6290.0,   # MI355X_MICROARCH.md: ~6.3 TB/s achievable
+            # caf_* timings are of ONE channel's launch; a multi-illuminator step runs all its channels in one launch per stage
+            "caf_channels_per_launch": len(refs) if multi else 1,
             "kernels": {k_: {"avg_ms_per_launch": v["ms"], "launches_per_step": v["launches_per_step"], "bound": v["bound"],
                              ("algorithmic_TFLOPs" if v["bound"] == "valu" else "algorithmic_GBps"):
                                  v["work"] / (v["ms"] * 1e-3) / (1e12 if v["bound"] == "valu" else 1e9)}

@@ -25,7 +25,12 @@ __global__ __launch_bounds__(DopCfg<F>::THREADS) void doppler_col_kernel(const f
     float2* lds = reinterpret_cast<float2*>(dop_smem);
     constexpr int Q = DopCfg<F>::Q, KT = DopCfg<F>::KT, F3 = DopCfg<F>::F3, E = DopCfg<F>::E;
     const int per_xcd = (total + 7) >> 3;
+#ifdef DOP_ROUND_ROBIN          // A/B: tiles in launch order (neighbouring tiles on different XCDs)
+    const int work = (int)blockIdx.x;
+    (void)per_xcd;
+#else
     const int work = (int)(blockIdx.x & 7u) * per_xcd + (int)(blockIdx.x >> 3);
+#endif
     if (work >= total) return;                                  // uniform
     const int ch = work / outs.per_ch, wch = work - ch * outs.per_ch;
     const int frame = wch / tiles, tile = wch - frame * tiles;

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
     // Workgroup -> work.  Workgroups reach the eight XCDs round-robin in launch order and every XCD has its own L2: workgroup
     // L (XCD L & 7, slot L >> 3 there) takes channel (L >> 3) % nref of chunk 8 ((L >> 3) / nref) + (L & 7).  The channels of
     // a multi-illuminator frame read the SAME surveillance windows and sit in consecutive slots of ONE XCD: one of them
-    // fetches a window from HBM, the others find it in that XCD's L2 (config 5, four channels: 222 -> 69 MB fetched per
+    // fetches a window from HBM, the others find it in that XCD's L2 (config 5, four channels: 219 -> 96 MB fetched per
     // surface, 301 -> 281 us per frame).  Chunks themselves keep going round the XCDs: giving every XCD a contiguous run of
     // segments instead (PRC_OPT_CAF_XCD_CONTIG = 1; neighbouring segments share half a window) measured 3-6 % SLOWER at
     // one channel and at four, configs 3 and 5 alike (profiles/r04_ab_log.md, call 12) -- eight distant streams instead of

@@ -79,8 +79,16 @@ md = [f"# Round {tag[1:].lstrip('0')} -- hardware counters (rocprofv3 --pmc, one
 for name, wl in (("pmc_cfg2", "cfg2"), ("pmc_cfg3", "cfg3"), ("pmc_cfg5", "cfg5")):
     line = load_line(name)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    rows = []
     for fcsv in glob.glob(os.path.join(E, name, "g*", "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(fcsv)):
+        rows += list(csv.DictReader(open(fcsv)))
+    # a kernel's launches of the STEP only: bench.py's per-kernel timing section launches one channel's surfaces at a time,
+    # a multi-illuminator step all channels at once (a four times larger grid) -- keep the largest grid seen per kernel
+    biggest = collections.defaultdict(int)
+    for r in rows:
+        biggest[short(r["Kernel_Name"])] = max(biggest[short(r["Kernel_Name"])], int(r["Grid_Size"]))
+    for r in rows:
+        if int(r["Grid_Size"]) == biggest[short(r["Kernel_Name"])]:
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     if not acc or not line:
         continue
@@ -101,10 +109,11 @@ for name, wl in (("pmc_cfg2", "cfg2"), ("pmc_cfg3", "cfg3"), ("pmc_cfg5", "cfg5"
         per_step = max(bk.get("launches_per_step", 1), 1)
         nill = 4 if wl == "cfg5" else 1
         bins = 5 if fam in ("ls_fir_subtract", "ls_solve") else 1
-        units = nframes * nill * bins / per_step if fam else float("nan")
+        chans = line.get("caf_channels_per_launch", 1) if fam in ("caf_segments", "caf_doppler") else 1
+        units = nframes * nill * bins / per_step * chans if fam else float("nan")
         fetch, write = 2 * c.get("FETCH_SIZE", 0) * 1e3, c.get("WRITE_SIZE", 0) * 1e3          # bytes per launch
         alg = bk.get("algorithmic_GBps", 0) * 1e9 * bk.get("avg_ms_per_launch", 0) * 1e-3      # bytes per bench launch
-        alg_unit = alg / units if fam and units else float("nan")
+        alg_unit = alg / (units / chans) if fam and units else float("nan")     # bench's own launch covers one channel's units
         wc = c.get("SQ_WAVE_CYCLES", 0) or 1
         md.append(f"| `{k[:56]}` | {nl} | {units:.0f} | {fetch / units / 1e6:.2f} | {write / units / 1e6:.2f} | {alg_unit / 1e6:.2f} | "
                   f"{(fetch + write) / units / alg_unit if alg_unit == alg_unit and alg_unit else float('nan'):.2f} | "
