@@ -181,6 +181,15 @@ def fm_suppression(L=64):
             "scene": f"FM-like reference (75 kHz deviation, 15 kHz audio), N={n}, {L + 10} taps, bins {bins}"}
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                               # noqa: BLE001 -- cosmetic
+        pass
+    sys.stdout.flush()
+
+
 def synth_raw_pinned(torch, nchunks, icl, fs_in, foff, device, seed=2026, per=16):
     """Raw interleaved int8 I,Q recordings of both channels in PINNED host memory, made on the device batch by batch
     (structure of passiveradar_amd.scene.make_raw_stream: band-limited noise offset_freq below the recording's centre,
@@ -333,6 +342,7 @@ def prconfig_main(args):
         result["cpu_baseline"] = {"value": 2.0 / t_cpu, "unit": "frames/s", "cores": 1, "kind": "port",
                                   "sample": f"two raw blocks per channel through front end, LS x5, CAF (np.roots artefact bypassed) "
                                             f"and CFAR on one core: {t_cpu:.1f} s"}
+    _flush_c_stdio()
     print(json.dumps(result), flush=True)
 
 
@@ -353,7 +363,8 @@ def main():
                     help="run LS and CAF back to back on one stream instead of pipelining sub-batches on two")
     ap.add_argument("--gather", default="auto", choices=["auto", "prc", "torch", "none"],
                     help="N>1: prc = prc_gather_frames (RCCL through the C ABI), torch = torch.distributed.gather, "
-                         "auto = prc when every rank could create the communicator, else torch")
+                         "auto = prc when every rank could create the communicator, else torch.  On ONE GPU an explicit "
+                         "prc runs the same gather plumbing through a communicator of one rank (self-test)")
     ap.add_argument("--gather-parts", type=int, default=4,
                     help="cfg4, N>1: gather a shard's maps in this many rounds, each as soon as its frames are done "
                          "(1 = one gather after the whole shard)")
@@ -461,8 +472,14 @@ def main():
 
     # ---- the one collective: gather of the maps to rank 0 ---------------------------------------------
     gather_mode = args.gather if (world > 1 and nill == 1) else "none"
+    if world == 1 and nill == 1 and args.gather == "prc":
+        # one GPU, asked for explicitly: the whole gather plumbing (cuts, events, receive buffers, prc_gather_frames)
+        # through a communicator of ONE rank -- what tests/test_gpu_stream.py runs; not a number of record
+        gather_mode = "prc"
     comm = None
-    if gather_mode in ("auto", "prc"):
+    if world == 1 and gather_mode == "prc":
+        comm = prstream.FrameComm(0, 1, prstream.FrameComm.unique_id())
+    elif gather_mode in ("auto", "prc"):
         ok = 1
         try:
             comm = prstream.FrameComm.from_torch_distributed()
@@ -483,17 +500,29 @@ def main():
             gshard = shard
         else:
             gshard = prstream.Shard(rank, world, gsize * world, rank * gsize, (rank + 1) * gsize, 0, gsize)
+        # persistent receive buffers, used in turn: four in the weak mode, whose gathers are issued sub-batch by sub-batch
+        # WHILE the step is being enqueued (the host only ever waits for the gather issued four blocks earlier, so the GPU
+        # always has two sub-batches of kernels queued ahead)
+        nrecv = 2 if strong else 4
         recv = [torch.empty((gshard.nchunks, F, R + 1), dtype=torch.complex64, device=device) if rank == 0 else None
-                for _ in range(2)]                   # two persistent receive buffers, used alternately
-    pending = [None, None]                           # work handle of the gather that last used each buffer
+                for _ in range(nrecv)]
+    else:
+        nrecv = 2
+    pending = [None] * nrecv                         # work handle of the gather that last used each buffer
     gcount = [0]
 
-    def gather(block):
-        k = gcount[0] & 1
+    last_gather = {}
+
+    def gather(block, ev=None):
+        k = gcount[0] % nrecv
         gcount[0] += 1
+        last_gather.update(k=k, m=int(block.shape[0]), first=block.storage_offset() // (F * (R + 1)))
         if pending[k] is not None:
             pending[k][1].wait()
-        s_comm.wait_stream(torch.cuda.current_stream())
+        if ev is not None:
+            s_comm.wait_event(ev)                    # the launch that completed this block's frames
+        else:
+            s_comm.wait_stream(torch.cuda.current_stream())
         sh, out = gshard, recv[k]
         if not strong and block.shape[0] != gsize:   # ragged last sub-batch: every rank sends the same shorter block
             m = int(block.shape[0])
@@ -509,7 +538,7 @@ def main():
                    if (strong and gather_mode != "none" and args.gather_parts > 1) else None)
 
     def drain():
-        for k in (0, 1):
+        for k in range(nrecv):
             if pending[k] is not None:
                 pending[k][1].wait()
                 pending[k] = None
@@ -549,6 +578,20 @@ def main():
             if nframes:
                 be.run(refs[0], srv_pad, nlocal, first, nframes, out=outs[p][0], cuts=cuts, on_frames=on_frames)
             on_frames(0, nframes, torch.cuda.current_stream().record_event())      # ranks with empty parts still take part
+            ev_g = torch.cuda.Event()
+            ev_g.record(s_comm)
+            gathered[p] = ev_g
+            return
+        if gather_mode != "none" and not strong and not multi and nframes:
+            # weak scaling: every sub-batch's maps leave for rank 0 as soon as the launch that completes them is enqueued,
+            # on the communication stream behind that launch's event -- the transfers ride under the rest of the step's
+            # kernels (before round 4 all 22 gathers of a step were issued after its last kernel and the host waited for
+            # them before it could enqueue the next step: compute and gather in series on rank 0)
+            def on_frames(lo, hi, ev):
+                for f0 in range(lo, hi, gsize):
+                    gather(outs[p][0][f0:min(f0 + gsize, hi)], ev)
+            cuts = list(range(gsize, nframes, gsize))
+            be.run(refs[0], srv_pad, nlocal, first, nframes, out=outs[p][0], cuts=cuts, on_frames=on_frames)
             ev_g = torch.cuda.Event()
             ev_g.record(s_comm)
             gathered[p] = ev_g
@@ -625,7 +668,13 @@ def main():
     if args.dump and world == 1 and nframes:
         last = outs[(stepno[0] - 1) % nsets]
         pick = sorted({0, min(1, nframes - 1), nframes // 2, nframes - 1})
-        np.savez(args.dump, frame_index=np.array(pick), seed0=seed0, nframes=nframes,
+        extra = {}
+        if gather_mode != "none" and last_gather:
+            # what the last gather of the step delivered (one GPU: this rank's block), and which frames it was
+            drain()
+            extra = {"gathered_block": recv[last_gather["k"]][:last_gather["m"]].cpu().numpy(),
+                     "gathered_first_frame": last_gather["first"], "gathers_per_step": gcount[0] // max(stepno[0], 1)}
+        np.savez(args.dump, frame_index=np.array(pick), seed0=seed0, nframes=nframes, **extra,
                  **{f"ill{i}_frames": o[pick].cpu().numpy() for i, o in enumerate(last)},
                  **{f"ill{i}_sums": o[:nframes].sum(dim=(1, 2)).cpu().numpy() for i, o in enumerate(last)})
 
@@ -802,12 +851,21 @@ def main():
                     "frames_per_s": 1.0 / per_frame,
                     "note": f"one np.roots(ones({q + 1})) timed on this box (LAPACK may use several cores), times the "
                             f"{R + 1} lag columns, plus the one-core path above"}
-        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         if comm is not None:
             comm.close()
         dist.destroy_process_group()
+    elif comm is not None:
+        drain()
+        comm.close()
+    # The JSON line is the LAST thing this job writes: RCCL prints a version banner through C stdio (fully buffered when
+    # stdout is a pipe, so it would otherwise appear at process exit, after the line) -- flush C stdio on every rank first
+    _flush_c_stdio()
+    if result is not None:
+        if world > 1:
+            time.sleep(1.0)                         # the other ranks' flushes (same point, no collective left) land first
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -170,7 +170,7 @@ def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, com
     async_op=True returns ``(result_or_None, work)``: ``work.wait()`` before touching the result (and
     before reusing ``local``)."""
     import torch
-    if shard.world == 1:
+    if shard.world == 1 and comm is None:
         if out is not None and out.data_ptr() != local.data_ptr():
             out.copy_(local)
             local = out

@@ -345,11 +345,15 @@ def test_bench_cfg4_maps_against_an_independent_pass(tmp_path):
     assert rel_err(got[list(d["frame_index"]).index(fi)], exp) < 1e-4
 
 
-def test_bench_default_workload_maps_against_an_independent_pass(tmp_path):
+@pytest.mark.parametrize("gather", ["none", "prc"])
+def test_bench_default_workload_maps_against_an_independent_pass(tmp_path, gather):
     """The HEADLINE path itself: bench.py's default workload at 600 frames -- three sub-batches of 256 (the
     last one ragged) alternating over the three LS plans / streams, the CAF on a fourth -- dumps the first, second, middle
     and last map and every frame's sum of its last timed step; an independent pass over the regenerated stream (batches of
-    five, LS and CAF back to back on one stream, one plan) must give the same maps"""
+    five, LS and CAF back to back on one stream, one plan) must give the same maps.  gather = "prc": the same step with the
+    N > 1 gather plumbing switched on through a communicator of ONE rank -- CAF launches cut at the sub-batch boundaries,
+    every block handed to prc_gather_frames on the communication stream behind its launch's event, four receive buffers in
+    turn -- which must not change a map (the multi-rank transfers themselves need more than one GPU)"""
     import subprocess
     import sys
     import torch
@@ -359,7 +363,8 @@ def test_bench_default_workload_maps_against_an_independent_pass(tmp_path):
     import bench
     dump = str(tmp_path / "cfg2.npz")
     r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--no-cpu", "--steps", "2", "--warmup", "1",
-                        "--frames", "600", "--dump", dump], capture_output=True, text=True, timeout=900, cwd=repo)
+                        "--frames", "600", "--dump", dump, "--gather", gather], capture_output=True, text=True, timeout=900,
+                       cwd=repo)
     assert r.returncode == 0, r.stderr[-2000:]
     d = np.load(dump)
     fs, n, R, F, _, _ = bench.WORKLOADS["cfg2"]
@@ -378,6 +383,11 @@ def test_bench_default_workload_maps_against_an_independent_pass(tmp_path):
     # every frame's sum (a coarse check that each of the 600 maps came from the right chunks): 131 584 cells whose 1e-6
     # differences add incoherently while the sum itself mostly cancels -- measured 1.2e-5 of the largest sum
     assert rel_err(d["ill0_sums"], maps.sum(dim=(1, 2)).cpu().numpy()) < 1e-4
+    if gather == "prc":
+        # the block the last prc_gather_frames call of the step delivered into its receive buffer IS those frames
+        f0, blk = int(d["gathered_first_frame"]), d["gathered_block"]
+        assert f0 + blk.shape[0] == nfr and int(d["gathers_per_step"]) >= 3
+        assert rel_err(blk, maps[f0:f0 + blk.shape[0]].cpu().numpy()) < 5e-6
 
 
 def test_stream_with_the_ls_filter_variant():
