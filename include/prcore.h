@@ -77,7 +77,10 @@ typedef enum prc_option {
     PRC_OPT_CAF_XCD_CONTIG = 7,   /* workgroup order of the 4096-point segment kernel, read per launch (A/B runs): 0 (default) =
                                      segments go round the XCDs in launch order, 1 = every XCD takes a contiguous run of them
                                      (measured slower on MI355X)                                                            */
-    PRC_OPT_COUNT_ = 8
+    PRC_OPT_CAF_PAIR_FRAMES = 8,  /* 4096-point segment kernel, frames overlapping by half, read per launch (A/B runs): 1 (default) =
+                                     the two frames that cover the same samples run in consecutive slots of one XCD (config 5: -2 %
+                                     at one channel, -3 % at four), 0 = frame after frame                                   */
+    PRC_OPT_COUNT_ = 9
 } prc_option;
 int prc_set_option(int32_t option, int64_t value);     /* PRC_EINVAL for an unknown option or a value out of range */
 int prc_get_option(int32_t option, int64_t* value);

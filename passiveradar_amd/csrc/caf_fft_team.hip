@@ -76,6 +76,9 @@ struct CafTeamArgs {
     int64_t y_ref_stride;
     int32_t nref, chunks_x, nchunks;   // channels; workgroup chunks per frame; chunks_x * nframes
     int32_t xcd_contig;                // 1: an XCD takes a contiguous run of chunks; 0: chunks go round the XCDs in launch order
+    int32_t pair_half;                 // > 0: frames overlap by half (= this many chunks): the two frames that cover the same
+                                       // samples run in consecutive slots of one XCD (PRC_OPT_CAF_PAIR_FRAMES)
+    int32_t nframes;
 };
 
 
@@ -97,9 +100,23 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
     const int per_xcd = (a.nchunks + 7) >> 3;
     const int slot = (int)(blockIdx.x >> 3);
     const int ch = slot % a.nref, ci = slot / a.nref;
-    const int chunk = a.xcd_contig ? (int)(blockIdx.x & 7u) * per_xcd + ci : ci * 8 + (int)(blockIdx.x & 7u);
-    if (ci >= per_xcd || chunk >= a.nchunks) return;            // uniform, before any barrier
-    const int b = chunk / a.chunks_x, bx = chunk - b * a.chunks_x;
+    int b, bx;
+    if (a.pair_half > 0) {
+        // 50 %-overlapped frames: position A of the stream (in chunks of half a frame) is covered by frame A / half (its
+        // first half) and by the frame before (its second half) -- the two take consecutive slots, like the channels, and
+        // share the reference and surveillance samples through the L2 (config 5, 16 frames: 285 -> 276 us per four-
+        // illuminator frame, 74 -> 72.4 us per surface at one channel; config 3: no difference)
+        const int k = ci & 1, A = (ci >> 1) * 8 + (int)(blockIdx.x & 7u);
+        if (A >= (a.nframes + 1) * a.pair_half) return;         // uniform, before any barrier
+        b = A / a.pair_half - k;
+        bx = A % a.pair_half + k * a.pair_half;
+        if (b < 0 || b >= a.nframes || bx >= a.chunks_x) return;
+    } else {
+        const int chunk = a.xcd_contig ? (int)(blockIdx.x & 7u) * per_xcd + ci : ci * 8 + (int)(blockIdx.x & 7u);
+        if (ci >= per_xcd || chunk >= a.nchunks) return;        // uniform, before any barrier
+        b = chunk / a.chunks_x;
+        bx = chunk - b * a.chunks_x;
+    }
     const float2* __restrict__ ref = a.refs[ch] + (int64_t)b * a.s.frame_stride;
     const float2* __restrict__ srv = a.s.srv + (int64_t)b * a.s.frame_stride;
     const float* __restrict__ win = a.s.window;
@@ -309,7 +326,14 @@ int caf_launch_fft_team_refs(const CafSegArgs& s, const float2* const* refs, int
     a.xcd_contig = (int)prc_opt(PRC_OPT_CAF_XCD_CONTIG);
     a.chunks_x = (s.freq_bins + a.segs - 1) / a.segs;
     a.nchunks = a.chunks_x * nframes;
-    dim3 grid((unsigned)(8 * ((a.nchunks + 7) / 8) * nref));
+    a.nframes = nframes;
+    a.pair_half = 0;
+    if (prc_opt(PRC_OPT_CAF_PAIR_FRAMES) && nframes >= 2 && (a.chunks_x & 1) == 0) {
+        const double shift = (double)s.frame_stride / ((double)s.q * a.segs);     // frame to frame, in chunks
+        if (shift > a.chunks_x / 2 - 1.0 && shift < a.chunks_x / 2 + 1.0) a.pair_half = a.chunks_x / 2;
+    }
+    dim3 grid(a.pair_half > 0 ? (unsigned)(8 * (((nframes + 1) * a.pair_half + 7) / 8) * 2 * nref)
+                              : (unsigned)(8 * ((a.nchunks + 7) / 8) * nref));
     const size_t lds = sizeof(float2) * FT_LDS_ELEMS;
     { int rc_ = prc_lds_optin(reinterpret_cast<const void*>(s.window ? &caf_fft_team_kernel<true> : &caf_fft_team_kernel<false>), (int)lds); if (rc_) return rc_; }
     if (s.window)

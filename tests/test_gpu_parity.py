@@ -941,3 +941,40 @@ def test_ls_plan_without_a_spectrum_cache(L):
     exp = O.LS_Filter_Multiple(ref, srv, L, fs, list(bins))
     assert rel_err(outs[0], exp) < TOL and rel_err(outs[1], exp) < TOL
     assert rel_err(outs[1], outs[0]) < 1e-5
+
+
+@pytest.mark.parametrize("nref", [1, 3])
+def test_caf_team_workgroup_orders_give_the_same_maps(nref):
+    """the 4096-point segment kernel's workgroup -> (frame, segment, channel) map has three forms (launch order, an XCD-
+    contiguous run of segments per XCD, the two frames that cover the same samples in consecutive slots): batched
+    50 %-overlapped frames, odd frame count, one and three channels -- bit-identical maps, and the oracle's for one frame"""
+    import torch
+    from passiveradar_amd import _lib, engine
+    n, R, F, nf = 1 << 17, 1024, 64, 5
+    refs, srv = scene.make_multi_scene(n // 2 * (nf + 1), 1e5, 100, [501 + i for i in range(nref)])
+    dr = [torch.from_numpy(r).cuda() for r in refs]
+    ds = torch.from_numpy(srv).cuda()
+    win = torch.from_numpy(np.kaiser(n, 5.0).astype(np.float32)).cuda()
+    results = []
+    for contig, pair in ((0, 0), (1, 0), (0, 1)):
+        o1 = _lib.set_option(_lib.OPT_CAF_XCD_CONTIG, contig)
+        o2 = _lib.set_option(_lib.OPT_CAF_PAIR_FRAMES, pair)
+        try:
+            plan = engine.CafPlan(n, R, F, nf * nref, _lib.CAF_FFT4096, multi="turns")
+            outs = [torch.zeros((nf, F, R + 1), dtype=torch.complex64, device="cuda") for _ in range(nref)]
+            if nref == 1:
+                plan.execute(dr[0], ds, outs[0], nf, n // 2, n, win)
+            else:
+                plan.execute_multi(dr, ds, outs, nf, n // 2, n, win)
+            torch.cuda.synchronize()
+            results.append([o.cpu().numpy() for o in outs])
+            plan.close()
+        finally:
+            _lib.set_option(_lib.OPT_CAF_XCD_CONTIG, o1)
+            _lib.set_option(_lib.OPT_CAF_PAIR_FRAMES, o2)
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert np.array_equal(a, b)
+    b = nf - 2
+    exp = O.fast_xambg(refs[-1][b * n // 2:b * n // 2 + n], srv[b * n // 2:b * n // 2 + n], R, F, n, np.kaiser(n, 5.0))
+    assert rel_err(results[0][-1][b], exp[:, :, 0]) < TIGHT
