@@ -417,10 +417,12 @@ class HipBackend:
         buf[self.C // 2:self.C // 2 + n].copy_(t, non_blocking=True)
         return buf
 
-    def front_end(self, raw, input_chunk_length, offset_freq, input_sample_rate, up, dn, max_blocks=32):
+    def front_end(self, raw, input_chunk_length, offset_freq, input_sample_rate, up, dn, max_blocks=32, block0=0, out=None):
         """SURVEY 8f next #1 -- main.py:105-166 for one channel, on the device: raw interleaved scalars
         (host array or device tensor; int8 / uint8 / int16 / float32) -> IF complex64 stream (device
-        tensor, blocks concatenated).  One fused kernel per batch of blocks."""
+        tensor, blocks concatenated).  One fused kernel per batch of blocks.  block0: index of the first block within
+        its recording (the block phases of main.py:125-131 continue across calls on consecutive pieces of one recording);
+        out: optional device tensor of nblocks * output_chunk_length complex64 to write into."""
         torch = self.torch
         from . import _lib
         t = raw if torch.is_tensor(raw) else torch.from_numpy(np.ascontiguousarray(raw))
@@ -437,8 +439,9 @@ class HipBackend:
                 plan = self._fe_plans[key] = self.engine.FrontendPlan(n_in, str(t.dtype).replace("torch.", ""),
                                                                       up, dn, max_blocks)
         per_block = n_in % (input_sample_rate // offset_freq)                       # main.py:125-130
-        phases = 2 * np.pi * np.arange(nblocks) * per_block * (offset_freq / input_sample_rate)
-        out = torch.empty(nblocks * plan.n_out, dtype=torch.complex64, device=self.device)
+        phases = 2 * np.pi * (np.arange(nblocks) + int(block0)) * per_block * (offset_freq / input_sample_rate)
+        if out is None:
+            out = torch.empty(nblocks * plan.n_out, dtype=torch.complex64, device=self.device)
         with torch.cuda.device(self.device):
             for b0 in range(0, nblocks, max_blocks):
                 nb = min(max_blocks, nblocks - b0)

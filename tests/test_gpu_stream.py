@@ -479,3 +479,27 @@ def test_prconfig_raw_to_frame_against_reference_output():
     C = cfg["output_chunk_length"]
     got = clean[C // 2:C // 2 + int(g["nblk"]) * C][::61].cpu().numpy()
     assert np.abs(got - g["cleaned_sub"]).max() / float(g["if_srv_rms"]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_front_end_in_pieces_continues_the_block_phases():
+    """front_end(block0=, out=): a recording converted piece by piece (bench.py --workload prconfig overlaps the host
+    link with the device this way) is the recording converted in one call, bit for bit -- the per-block phase of
+    main.py:125-131 is a function of the block's index in the recording, not in the call."""
+    import json
+    import torch
+    from passiveradar_amd import scene, stream as prstream
+    cfg = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_prconfig.json")))
+    icl = 2 * 4096 * 3
+    rr, _ = scene.make_raw_stream(7, icl, cfg["input_sample_rate"], cfg["offset_freq"], scene.scene_seed(5))
+    be = prstream.HipBackend(4096, 16, 32, cfg["IF_sample_rate"], batch=8, device=torch.device("cuda", 0), clutter=None)
+    args = (icl, cfg["offset_freq"], cfg["input_sample_rate"], cfg["resamp_up"], cfg["resamp_dn"])
+    whole = be.front_end(rr, *args, max_blocks=4)
+    n_out = whole.shape[0] // 7
+    out = torch.zeros(7 * n_out + 10, dtype=torch.complex64, device="cuda")
+    for b0, m in ((0, 3), (3, 1), (4, 3)):
+        got = be.front_end(rr[b0 * icl:(b0 + m) * icl], *args, max_blocks=4, block0=b0, out=out[5 + b0 * n_out:5 + (b0 + m) * n_out])
+        assert got.data_ptr() == out[5 + b0 * n_out:].data_ptr()
+    torch.cuda.synchronize()
+    assert torch.equal(out[5:5 + 7 * n_out], whole)
+    assert float(out[:5].abs().max()) == 0.0 and float(out[-5:].abs().max()) == 0.0
