@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRC_VERSION 400   /* 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
+#define PRC_VERSION 401   /* 401: prc_comm_loopback; 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
                              prc_comm_count; 310: prc_ls_desc.method = 4, NLMS up to 8192 taps */
 
 typedef enum prc_status {
@@ -314,6 +314,11 @@ int prc_comm_rccl_version(int32_t* version);                  /* ncclGetVersion 
 /* what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank): the number of ranks it connected and
  * this process's rank among them -- a bench line can show that N ranks really met */
 int prc_comm_count(const prc_comm* comm, int32_t* nranks, int32_t* rank);
+/* Link check of the point-to-point path on THIS rank alone: nfloats float32 from `send` to `recv` (both DEVICE, not
+ * overlapping) as one grouped ncclSend + ncclRecv with this rank as its own peer -- the same RCCL calls, datatype and
+ * stream discipline as prc_gather_frames, runnable on a communicator of any size including one (a one-GPU box), so a host
+ * can check the RCCL binding before the first gather.  Enqueued on `stream`; not a collective. */
+int prc_comm_loopback(prc_comm* comm, const void* send, void* recv, int64_t nfloats, void* stream);
 int prc_comm_destroy(prc_comm* comm);
 /* send: this rank's frames_per_rank_host[rank] frames of frame_elems complex64 (DEVICE).  recv (root
  * only, DEVICE): sum(frames_per_rank_host) frames, rank r's block at frame offset sum_{q<r}.  Blocks may

@@ -120,6 +120,7 @@ _SIGNATURES = {
     "prc_comm_destroy": (C.c_int, [C.c_void_p]),
     "prc_comm_rccl_version": (C.c_int, [C.POINTER(C.c_int32)]),
     "prc_comm_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "prc_comm_loopback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "prc_gather_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.c_void_p,
                                     C.c_int32, C.c_void_p]),
 }

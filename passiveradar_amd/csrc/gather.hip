@@ -147,6 +147,22 @@ extern "C" int prc_comm_destroy(prc_comm* c) {
     return PRC_OK;
 }
 
+extern "C" int prc_comm_loopback(prc_comm* c, const void* send, void* recv, int64_t nfloats, void* stream_) {
+    PRC_REQUIRE(c && send && recv && nfloats > 0, PRC_EINVAL, "prc_comm_loopback: null argument or empty message");
+    hipStream_t stream = (hipStream_t)stream_;
+    std::lock_guard<std::mutex> lk(c->mtx);
+    // a send to oneself only completes against a receive posted in the same group
+    PRC_RCCL(g_rccl.GroupStart());
+    nccl_result_t a = g_rccl.Send(send, (size_t)nfloats, NCCL_FLOAT32, c->rank, c->comm, stream);
+    nccl_result_t b = a == 0 ? g_rccl.Recv(recv, (size_t)nfloats, NCCL_FLOAT32, c->rank, c->comm, stream) : 0;
+    nccl_result_t end = g_rccl.GroupEnd();
+    if (a != 0 || b != 0 || end != 0) {
+        prc_set_error("prc_comm_loopback: RCCL send/receive to self failed: %s", g_rccl.GetErrorString(a ? a : (b ? b : end)));
+        return PRC_EHIP;
+    }
+    return PRC_OK;
+}
+
 // RCCL usage, checked against its rules for point-to-point operations:
 //  * a peer issues ONE ncclSend per gather (no group needed for a single operation); the root issues one ncclRecv per
 //    peer inside ncclGroupStart/End, so the receives are posted together and progress concurrently -- a root that posted

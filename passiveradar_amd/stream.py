@@ -113,6 +113,17 @@ class FrameComm:
         _lib.check(_lib.lib().prc_comm_count(self._h, C.byref(n), C.byref(r)))
         return int(n.value), int(r.value)
 
+    def loopback(self, send, recv, stream=None):
+        """prc_comm_loopback: ``send`` -> ``recv`` (device tensors of equal size, float32 or complex64) through RCCL's
+        point-to-point path with this rank as its own peer; enqueued on ``stream`` (default: the current torch stream)"""
+        from . import _lib
+        if send.numel() * send.element_size() != recv.numel() * recv.element_size() or not (send.is_contiguous() and recv.is_contiguous()):
+            raise ValueError("loopback: send and recv must be contiguous and of equal size")
+        nfloats = send.numel() * send.element_size() // 4
+        import ctypes as C
+        sp = _lib.torch_stream_ptr(send.device) if stream is None else C.c_void_p(stream.cuda_stream)
+        _lib.check(_lib.lib().prc_comm_loopback(self._h, send.data_ptr(), recv.data_ptr(), nfloats, sp))
+
     def close(self):
         if getattr(self, "_h", None):
             from . import _lib

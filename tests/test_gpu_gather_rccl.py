@@ -36,6 +36,11 @@ def _worker(rank, world, port, q):
         comm = FrameComm.from_torch_distributed()
         # what RCCL itself says about the communicator (prc_comm_count): the number of ranks it connected, this rank's id
         assert comm.count() == (world, rank), comm.count()
+        probe = torch.arange(1000, dtype=torch.float32, device=dev) + rank
+        echo = torch.zeros_like(probe)
+        comm.loopback(probe, echo)                # the self-peer link check on a communicator of several ranks
+        torch.cuda.synchronize()
+        assert torch.equal(probe, echo)
         F, cols = 8, 5
         # ragged blocks (ceil split of 2 * world + 1 frames), root 0 and root world - 1
         total = 2 * world + 1

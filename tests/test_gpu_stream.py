@@ -249,6 +249,38 @@ def test_prc_gather_frames_single_rank():
     comm.close()
 
 
+def test_prc_comm_loopback_moves_data_through_rccl_on_one_gpu():
+    """prc_comm_loopback: the calls prc_gather_frames makes between ranks -- ncclGroupStart, ncclSend, ncclRecv, ncclGroupEnd
+    through the run-time binding, float32 counts, one stream -- executed on a one-GPU box with the rank as its own peer: a
+    wrong signature, datatype code or count unit in the binding shows here and not on the first multi-GPU run.  Sizes from
+    one float to one config-2 map and a non-default stream; a complex64 block travels as float pairs."""
+    import torch
+    from passiveradar_amd.stream import FrameComm
+    comm = FrameComm(0, 1, FrameComm.unique_id())
+    assert comm.count() == (1, 0)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for shape, dt in (((1,), torch.float32), ((1000, 3), torch.float32), ((3, 512, 257), torch.complex64)):
+        src = torch.randn(shape, dtype=torch.float32, device="cuda", generator=g) if dt == torch.float32 else \
+            torch.view_as_complex(torch.randn(shape + (2,), dtype=torch.float32, device="cuda", generator=g))
+        dst = torch.zeros_like(src)
+        comm.loopback(src, dst)
+        torch.cuda.synchronize()
+        assert torch.equal(src, dst), shape
+    st = torch.cuda.Stream()
+    src = torch.randn((1 << 20,), device="cuda", generator=g)
+    dst = torch.zeros_like(src)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        src2 = src * 2.0                                   # produced on the stream the transfer is enqueued on
+        comm.loopback(src2, dst, stream=st)
+        back = dst + 1.0                                   # consumed on it
+    st.synchronize()
+    assert torch.equal(back, src * 2.0 + 1.0)
+    with pytest.raises(ValueError):
+        comm.loopback(src, dst[:10])
+    comm.close()
+
+
 def test_four_illuminator_step_equals_four_single_cafs():
     """BASELINE config 5's structure (q = 4096, R = 2048: the same segment / lag-block shape as the full-size
     2048 x 2048 surface, fewer Doppler rows): four reference channels against ONE surveillance channel over a
