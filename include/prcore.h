@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRC_VERSION 401   /* 401: prc_comm_loopback; 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
+#define PRC_VERSION 401   /* 401: prc_comm_loopback, PRC_OPT_FE_METHOD; 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
                              prc_comm_count; 310: prc_ls_desc.method = 4, NLMS up to 8192 taps */
 
 typedef enum prc_status {
@@ -80,7 +80,10 @@ typedef enum prc_option {
     PRC_OPT_CAF_PAIR_FRAMES = 8,  /* 4096-point segment kernel, frames overlapping by half, read per launch (A/B runs): 1 (default) =
                                      the two frames that cover the same samples run in consecutive slots of one XCD (config 5: -2 %
                                      at one channel, -3 % at four), 0 = frame after frame                                   */
-    PRC_OPT_COUNT_ = 9
+    PRC_OPT_FE_METHOD = 9,        /* front-end kernel, read per launch: 0 (default) = the group form (`up` outputs per thread, taps
+                                     through the scalar unit) where it applies (up <= 16, window within LDS), else one output per
+                                     thread; 1 = one output per thread; 2 = the group form or PRC_EUNSUPPORTED                */
+    PRC_OPT_COUNT_ = 10
 } prc_option;
 int prc_set_option(int32_t option, int64_t value);     /* PRC_EINVAL for an unknown option or a value out of range */
 int prc_get_option(int32_t option, int64_t* value);

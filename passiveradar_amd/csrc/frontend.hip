@@ -31,12 +31,22 @@ struct FeArgs {
     int32_t up, dn, J, n_pre_remove;
     int32_t mix;              // apply the frequency shift
     int32_t opw;              // outputs per workgroup (<= FE_THREADS; fewer when the decimation ratio is large)
+    int32_t src;              // prc_raw_dtype, for the kernels that take it at run time (SRC = FE_SRC_RT)
     PhaseRamp pr;
 };
+#define FE_SRC_RT 99
 
 template <int SRC>
-__device__ __forceinline__ float2 fe_load(const void* raw, int64_t i) {
-    if (SRC == PRC_RAW_I8) {
+__device__ __forceinline__ float2 fe_load(const void* raw, int64_t i, int src = 0) {
+    if (SRC == FE_SRC_RT) {                 // the type is a (wave-uniform) kernel argument: one scalar branch per sample
+        switch (src) {
+            case PRC_RAW_I8: return fe_load<PRC_RAW_I8>(raw, i);
+            case PRC_RAW_U8: return fe_load<PRC_RAW_U8>(raw, i);
+            case PRC_RAW_I16: return fe_load<PRC_RAW_I16>(raw, i);
+            case PRC_RAW_F32: return fe_load<PRC_RAW_F32>(raw, i);
+            default: return fe_load<PRC_RAW_C64>(raw, i);
+        }
+    } else if (SRC == PRC_RAW_I8) {
         const signed char* p = (const signed char*)raw;
         return make_float2((float)p[2 * i], (float)p[2 * i + 1]);
     } else if (SRC == PRC_RAW_U8) {
@@ -53,15 +63,86 @@ __device__ __forceinline__ float2 fe_load(const void* raw, int64_t i) {
     }
 }
 
-// tuned sample i of the block, in double (reference: complex128 after the array phase offset)
+// sin / cos of a phase of up to ~1e9 rad to float32 accuracy: quadrant reduction in double (the argument is the
+// reference's float32 ramp plus a double block phase, 6e5 rad at the end of a PRconfig.yaml block, so the reduction cannot
+// be done in float32), polynomial kernels on |r| <= pi/4 in float32 (truncation 2e-9 / 1e-10, rounding 6e-8).  The
+// reference keeps the tuned block in complex128 up to resample_poly; the FIR here runs on float32 samples, so the
+// rotation is only observable to that rounding.  ~30 instructions against the ~300 of a double sincos with its
+// large-argument path.
+// Both polynomials advance in ONE packed instruction per Horner step (sin r = r + r r^2 S(r^2) in the low half, cos r =
+// 1 + r^2 C(r^2) in the high half: five v_pk_fma_f32 for the ten scalar ones), the quadrant is applied as sign bits, and
+// the complex product is the two packed instructions of fft_pk.h's pk_cmul (the same roundings as written out there).
+typedef float v2f __attribute__((ext_vector_type(2)));   // a complex64 in an even VGPR pair: v_pk_*_f32 work on both halves
+__device__ __forceinline__ v2f fe_sincos(double x) {     // (cos x, sin x)
+    const double q = rint(x * 0.63661977236758134308);
+    double r = fma(-q, 1.5707963267948965580, x);
+    r = fma(-q, 6.123233995736766036e-17, r);
+    const float rf = (float)r;
+    const int qi = (int)q;
+    const float r2 = rf * rf;
+    const v2f r22 = v2f{r2, r2};
+    v2f P = __builtin_elementwise_fma(v2f{2.7557314297e-6f, -2.7557314297e-7f}, r22, v2f{-1.9841270114e-4f, 2.4801587642e-5f});
+    P = __builtin_elementwise_fma(P, r22, v2f{8.3333337680e-3f, -1.3888889225e-3f});
+    P = __builtin_elementwise_fma(P, r22, v2f{-1.6666667163e-1f, 4.1666667908e-2f});
+    P = __builtin_elementwise_fma(P, r22, v2f{0.f, -0.5f});          // low: r^2 S (an exact +0); high: the next step of C
+    P = __builtin_elementwise_fma(P, v2f{rf, r2}, v2f{rf, 1.0f});    // (sin r, cos r)
+    // x = r + q pi/2: odd q swaps the two; sin is negative in quadrants 2, 3, cos in 1, 2 (bit 1 of q, of q + 1)
+    const unsigned t = (unsigned)qi << 30;
+    const float ss = (qi & 1) ? P.y : P.x, cc = (qi & 1) ? P.x : P.y;
+    return v2f{__uint_as_float(__float_as_uint(cc) ^ ((t + 0x40000000u) & 0x80000000u)),
+               __uint_as_float(__float_as_uint(ss) ^ (t & 0x80000000u))};
+}
+
+// tuned sample i of the block (reference: complex128 after the array phase offset; rounded to float32 here, the
+// type the resampler's FIR runs in)
+__device__ __forceinline__ float2 fe_rotate(const FeArgs& a, float2 v, int64_t i, double blk_phase) {
+    if (!a.mix) return v;
+    const float ph32 = (a.pr.a32 * (float)(int)i) * a.pr.rcp32;  // float32 ramp, as the reference (n_in < 2^31: plan creation)
+    const v2f t = fe_sincos((double)ph32 + blk_phase), x = v2f{v.x, v.y};
+    v2f p, d;                                                    // x t = (x.x t.x - x.y t.y, x.y t.x + x.x t.y)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p) : "v"(x), "v"(t));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(x), "v"(t), "v"(p));
+    return make_float2(d.x, d.y);
+}
 template <int SRC>
-__device__ __forceinline__ double2 fe_tuned(const FeArgs& a, const void* raw, int64_t i, double blk_phase) {
-    const float2 v = fe_load<SRC>(raw, i);
-    if (!a.mix) return make_double2(v.x, v.y);
-    const float ph32 = (a.pr.a32 * (float)i) * a.pr.rcp32;      // float32 ramp, as the reference
-    double s, c;
-    sincos((double)ph32 + blk_phase, &s, &c);
-    return make_double2((double)v.x * c - (double)v.y * s, (double)v.x * s + (double)v.y * c);
+__device__ __forceinline__ float2 fe_tuned(const FeArgs& a, const void* raw, int64_t i, double blk_phase) {
+    return fe_rotate(a, fe_load<SRC>(raw, i, a.src), i, blk_phase);
+}
+
+// 'line' extension of upfirdn: xe[i] = x[0] + i*slope (i < 0),  x[n-1] + (i-(n-1))*slope (i >= n)
+struct FeLine {
+    double2 x0, xl, slope;
+};
+template <int SRC>
+__device__ __forceinline__ FeLine fe_line(const FeArgs& a, const void* raw, double blk_phase) {
+    FeLine l;
+    const float2 f0 = fe_tuned<SRC>(a, raw, 0, blk_phase), fl = fe_tuned<SRC>(a, raw, a.n_in - 1, blk_phase);
+    l.x0 = make_double2(f0.x, f0.y);
+    l.xl = make_double2(fl.x, fl.y);
+    const double inv = a.n_in > 1 ? 1.0 / (double)(a.n_in - 1) : 0.0;
+    l.slope = make_double2((l.xl.x - l.x0.x) * inv, (l.xl.y - l.x0.y) * inv);
+    return l;
+}
+template <int SRC>
+__device__ __forceinline__ float2 fe_extended(const FeArgs& a, const void* raw, int64_t i, double blk_phase, const FeLine& l) {
+    if (i < 0) return make_float2((float)(l.x0.x + (double)i * l.slope.x), (float)(l.x0.y + (double)i * l.slope.y));
+    if (i >= a.n_in) {
+        const double d = (double)(i - (a.n_in - 1));
+        return make_float2((float)(l.xl.x + d * l.slope.x), (float)(l.xl.y + d * l.slope.y));
+    }
+    return fe_tuned<SRC>(a, raw, i, blk_phase);
+}
+
+template <int SRC>
+__device__ __forceinline__ const void* fe_block(const FeArgs& a, int b) {
+    if (SRC == FE_SRC_RT) {
+        const int64_t bytes = a.src <= PRC_RAW_U8 ? 1 : (a.src == PRC_RAW_I16 ? 2 : (a.src == PRC_RAW_F32 ? 4 : 8));
+        return (const char*)a.raw + (int64_t)b * a.raw_stride * bytes;
+    }
+    if (SRC == PRC_RAW_I8 || SRC == PRC_RAW_U8) return (const char*)a.raw + (int64_t)b * a.raw_stride;
+    if (SRC == PRC_RAW_I16) return (const short*)a.raw + (int64_t)b * a.raw_stride;
+    if (SRC == PRC_RAW_F32) return (const float*)a.raw + (int64_t)b * a.raw_stride;
+    return (const float2*)a.raw + (int64_t)b * a.raw_stride;
 }
 
 template <int SRC>
@@ -71,11 +152,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FeArgs a) {
     float2* X = reinterpret_cast<float2*>(H + ((a.J * a.up + 1) & ~1));   // staged tuned inputs
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    const void* raw;
-    if (SRC == PRC_RAW_I8 || SRC == PRC_RAW_U8) raw = (const char*)a.raw + (int64_t)b * a.raw_stride;
-    else if (SRC == PRC_RAW_I16) raw = (const short*)a.raw + (int64_t)b * a.raw_stride;
-    else if (SRC == PRC_RAW_F32) raw = (const float*)a.raw + (int64_t)b * a.raw_stride;
-    else raw = (const float2*)a.raw + (int64_t)b * a.raw_stride;
+    const void* raw = fe_block<SRC>(a, b);
     const double blk_phase = (a.mix && a.phases) ? a.phases[b] : 0.0;
     for (int i = tid; i < a.J * a.up; i += FE_THREADS) H[i] = a.taps[i];
 
@@ -86,21 +163,8 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FeArgs a) {
     const int64_t i_hi = ((m1 - 1 + a.n_pre_remove) * a.dn) / a.up;      // newest input of the last output
     const int64_t i_lo = ((m0 + a.n_pre_remove) * a.dn) / a.up - (a.J - 1);
     const int span = (int)(i_hi - i_lo + 1);
-    // 'line' extension: xe[i] = x[0] + i*slope (i < 0),  x[n-1] + (i-(n-1))*slope (i >= n)
-    const double2 x0 = fe_tuned<SRC>(a, raw, 0, blk_phase);
-    const double2 xl = fe_tuned<SRC>(a, raw, a.n_in - 1, blk_phase);
-    const double inv = a.n_in > 1 ? 1.0 / (double)(a.n_in - 1) : 0.0;
-    const double2 slope = make_double2((xl.x - x0.x) * inv, (xl.y - x0.y) * inv);
-    for (int k = tid; k < span; k += FE_THREADS) {
-        const int64_t i = i_lo + k;
-        double2 v;
-        if (i < 0) v = make_double2(x0.x + (double)i * slope.x, x0.y + (double)i * slope.y);
-        else if (i >= a.n_in) {
-            const double d = (double)(i - (a.n_in - 1));
-            v = make_double2(xl.x + d * slope.x, xl.y + d * slope.y);
-        } else v = fe_tuned<SRC>(a, raw, i, blk_phase);
-        X[k] = make_float2((float)v.x, (float)v.y);
-    }
+    const FeLine line = fe_line<SRC>(a, raw, blk_phase);
+    for (int k = tid; k < span; k += FE_THREADS) X[k] = fe_extended<SRC>(a, raw, i_lo + k, blk_phase, line);
     __syncthreads();
     const int64_t m = m0 + tid;
     if (tid >= a.opw || m >= a.n_out) return;
@@ -119,10 +183,179 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FeArgs a) {
     a.out[(int64_t)b * a.out_stride + m] = acc;
 }
 
+
+// ---- the group form (round 4): `up` consecutive outputs per thread -------------------------------------------------
+// Output m = up N + q (N: group, q < up) is  y = sum_r hz[s_q - up r] xe[dn N + r],  s_q = (q + n_pre_remove) dn, the
+// same sum as above with the tap index written against the input offset r from dn N.  Two things follow.  (1) The taps
+// an input meets, hz[s_q - up r] for q = 0 .. up-1, depend on r alone, not on the group: a thread that owns a whole
+// group reads each input ONCE from LDS and feeds `up` accumulators, and the taps are the same for every lane -- they
+// come through the scalar unit from a table T[row][q] (row = r_hi - r, zero where the index leaves the filter) the
+// plan made on the host.  Against one output per thread that is 1/up of the LDS reads and no tap reads at all (the
+// per-output kernel is bound by its two LDS reads per multiply-add); the price is the multiply-adds on the zero
+// corners of T, (dn (up-1)/up) of J + dn (up-1)/up rows (37 % at 13:119).  (2) A wavefront of 64 groups spans 64 dn
+// inputs (61 KB at 13:119), so the eight wavefronts of a workgroup share ONE window and split its rows (two workgroups
+// per CU = four wavefronts per SIMD); the partial sums meet in LDS, added in wavefront order every time, and leave as
+// whole 128-byte lines.
+// Inputs are staged tuned, as above.  dn even: a lane stride of dn complex samples would hit dn/gcd banks only; the
+// window is stored with one pad sample per dn.
+#define FEG_G 64
+#ifndef FEG_WAVES
+#define FEG_WAVES 8        // wavefronts per workgroup: they share one window and split its rows
+#endif
+#define FEG_THREADS (64 * FEG_WAVES)
+struct FegArgs {
+    const float* T;      // [FEG_WAVES * rows_per_wave][16]
+    int32_t rows_per_wave, r_first;   // r_first: input offset r of the window's first sample (= r_hi - (FEG_WAVES rows_per_wave - 1))
+    int32_t lane_stride, pad, span;   // span: staged samples per workgroup
+    float inv_dn;
+};
+
+#ifndef FEG_CHUNK
+#define FEG_CHUNK 8      // raw samples a thread has in flight before it starts rotating them
+#endif
+__device__ __forceinline__ int feg_at(const FeArgs& a, const FegArgs& g, int k) {
+    if (!g.pad) return k;
+    int nk = (int)((float)k * g.inv_dn);
+    if (nk * a.dn > k) --nk;
+    if ((nk + 1) * a.dn <= k) ++nk;
+    return k + nk;
+}
+template <int SRC, bool EDGE>
+__device__ __forceinline__ void feg_stage(const FeArgs& a, const FegArgs& g, float2* X, const void* raw, int64_t i_w,
+                                          double blk_phase, int tid) {
+    // FEG_CHUNK loads per thread are issued before the first rotation (a load-rotate-store chain per sample leaves the
+    // wavefront waiting on HBM once per sample).  Indices are clamped, not predicated: straight-line code, and at a
+    // block end (EDGE: two workgroups per block) the clamped sample is replaced by the 'line' extension afterwards.
+    FeLine line;
+    if (EDGE) line = fe_line<SRC>(a, raw, blk_phase);
+    const int last = g.span - 1;
+    for (int k0 = tid; k0 < g.span; k0 += FEG_THREADS * FEG_CHUNK) {
+        float2 v[FEG_CHUNK];
+#pragma unroll
+        for (int c = 0; c < FEG_CHUNK; ++c) {
+            int64_t i = i_w + min(k0 + c * FEG_THREADS, last);
+            if (EDGE) i = i < 0 ? 0 : (i >= a.n_in ? a.n_in - 1 : i);
+            v[c] = fe_load<SRC>(raw, i, a.src);
+        }
+#pragma unroll
+        for (int c = 0; c < FEG_CHUNK; ++c) {
+            const int k = k0 + c * FEG_THREADS;
+            const int64_t i = i_w + k;
+#ifdef FEG_EXP_NOROT                  // timing ablation, never shipped: the staging without its rotations
+            float2 t = v[c];
+#else
+            float2 t = fe_rotate(a, v[c], i, blk_phase);
+#endif
+            if (EDGE) {
+                if (i < 0) t = make_float2((float)(line.x0.x + (double)i * line.slope.x), (float)(line.x0.y + (double)i * line.slope.y));
+                else if (i >= a.n_in) {
+                    const double d = (double)(i - (a.n_in - 1));
+                    t = make_float2((float)(line.xl.x + d * line.slope.x), (float)(line.xl.y + d * line.slope.y));
+                }
+            }
+            if (k <= last) X[feg_at(a, g, k)] = t;
+        }
+    }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group_kernel(FeArgs a, FegArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* X = reinterpret_cast<float2*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const void* raw = fe_block<FE_SRC_RT>(a, b);
+    const double blk_phase = (a.mix && a.phases) ? a.phases[b] : 0.0;
+    const int64_t N0 = (int64_t)blockIdx.x * FEG_G;                 // first group of the workgroup
+    const int64_t i_w = N0 * a.dn + g.r_first;                      // input index of the window's first sample
+    // staging: as many instructions as the FIR (one rotation per input sample), so the loop is specialised outside --
+    // by sample type, and by whether the window touches a block end (the 'line' extension) -- not per sample
+    const bool inside = i_w >= 0 && i_w + g.span <= a.n_in;
+#define FEG_STAGE(S)                                                                                         \
+    case S:                                                                                                  \
+        if (inside) feg_stage<S, false>(a, g, X, raw, i_w, blk_phase, tid);                                  \
+        else feg_stage<S, true>(a, g, X, raw, i_w, blk_phase, tid);                                          \
+        break;
+    switch (a.src) {
+        FEG_STAGE(PRC_RAW_I8) FEG_STAGE(PRC_RAW_U8) FEG_STAGE(PRC_RAW_I16) FEG_STAGE(PRC_RAW_F32)
+        default:
+            if (inside) feg_stage<PRC_RAW_C64, false>(a, g, X, raw, i_w, blk_phase, tid);
+            else feg_stage<PRC_RAW_C64, true>(a, g, X, raw, i_w, blk_phase, tid);
+    }
+#undef FEG_STAGE
+    __syncthreads();
+    v2f acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = v2f{0.f, 0.f};
+    const float2* xl = X + lane * g.lane_stride;
+    const int row0 = w * g.rows_per_wave;
+    // two rows per trip: 2 x 16 taps through the scalar unit, two inputs from LDS, 2 NQ packed multiply-adds.  A row's
+    // input sits o = (rows - 1 - row) samples after the lane's first one (plus one pad sample per dn of them when dn is
+    // even): o, o / dn and o % dn are carried in scalar registers, nothing is looked up.
+    int o = FEG_WAVES * g.rows_per_wave - 1 - row0;
+    int od = o / a.dn, om = o - od * a.dn;
+#ifdef FEG_EXP_NOFIR                      // timing ablation, never shipped: one trip of the row loop
+    for (int rr = 0; rr < 2; rr += 2) {
+#else
+#pragma unroll 1
+    for (int rr = 0; rr < g.rows_per_wave; rr += 2) {
+#endif
+        const float* __restrict__ tr = g.T + (size_t)(row0 + rr) * 16;         // wave-uniform
+        const int off0 = o + (g.pad ? od : 0);
+        --o;
+        if (--om < 0) {
+            om += a.dn;
+            --od;
+        }
+        const int off1 = o + (g.pad ? od : 0);
+        --o;
+        if (--om < 0) {
+            om += a.dn;
+            --od;
+        }
+        const float2 x0 = xl[off0], x1 = xl[off1];
+        const v2f xa = v2f{x0.x, x0.y}, xb = v2f{x1.x, x1.y};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_elementwise_fma(v2f{tr[q], tr[q]}, xa, acc[q]);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_elementwise_fma(v2f{tr[16 + q], tr[16 + q]}, xb, acc[q]);
+    }
+    __syncthreads();                                                // the window is dead: its LDS takes the partial sums
+    // [wave][lane][q] at an odd pitch: a lane's `up` sums are stored pitch samples from its neighbour's (b64 stores,
+    // conflict-free for an odd pitch) and read back as what they are, consecutive outputs ([wave][q][lane] measured 68 %
+    // of all LDS cycles of the kernel as bank conflicts: thirteen lanes of a read on one bank)
+    float2* P = reinterpret_cast<float2*>(smem_raw);
+    const int pitch = a.up | 1;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) P[(w * FEG_G + lane) * pitch + q] = make_float2(acc[q].x, acc[q].y);
+    __syncthreads();
+    const int64_t M0 = N0 * a.up;
+    float2* out = a.out + (int64_t)b * a.out_stride;
+    for (int o = tid; o < FEG_G * a.up; o += FEG_THREADS) {
+        const int64_t m = M0 + o;
+        if (m >= a.n_out) break;
+        const int n = o / a.up, q = o - n * a.up;
+        const int at = n * pitch + q;
+        float2 sum = P[at];
+#pragma unroll
+        for (int v = 1; v < FEG_WAVES; ++v) {                       // wavefront 0's rows first, in order, every time
+            const float2 pv = P[v * FEG_G * pitch + at];
+            sum.x += pv.x;
+            sum.y += pv.y;
+        }
+        out[m] = sum;
+    }
+}
+
 struct prc_frontend_plan {
     prc_frontend_desc desc;
     float* d_taps = nullptr;     // polyphase layout
     double* d_phases = nullptr;  // max_blocks
+    float* d_T = nullptr;        // group form: tap rows (nullptr: up > 16 or the window does not fit LDS)
+    FegArgs g = {};
+    size_t g_lds = 0;
     int J = 0;
     int64_t n_in = 0, n_out = 0;
     std::mutex mtx;
@@ -132,14 +365,15 @@ extern "C" int prc_frontend_plan_destroy(prc_frontend_plan* p) {
     if (!p) return PRC_OK;
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_phases) (void)hipFree(p->d_phases);
+    if (p->d_T) (void)hipFree(p->d_T);
     delete p;
     return PRC_OK;
 }
 
 extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_frontend_desc* d) {
     PRC_REQUIRE(plan && d, PRC_EINVAL, "prc_frontend_plan_create: null argument");
-    PRC_REQUIRE(d->n_in > 1 && d->up > 0 && d->down > 0 && d->ntaps > 0 && d->taps_host && d->max_blocks > 0,
-                PRC_EINVAL, "prc_frontend_plan_create: bad size");
+    PRC_REQUIRE(d->n_in > 1 && d->n_in < ((int64_t)1 << 30) && d->up > 0 && d->down > 0 && d->ntaps > 0 && d->taps_host &&
+                d->max_blocks > 0, PRC_EINVAL, "prc_frontend_plan_create: bad size (blocks of 2 .. 2^30 complex samples)");
     PRC_REQUIRE(d->raw_dtype >= PRC_RAW_I8 && d->raw_dtype <= PRC_RAW_C64, PRC_EINVAL,
                 "prc_frontend_plan_create: unknown raw dtype %d", d->raw_dtype);
     prc_frontend_plan* p = new prc_frontend_plan();
@@ -154,6 +388,41 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
     hipError_t e = hipMalloc(&p->d_taps, sizeof(float) * poly.size());
     if (e == hipSuccess) e = hipMemcpy(p->d_taps, poly.data(), sizeof(float) * poly.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->d_phases, sizeof(double) * d->max_blocks);
+    // the group form's tables: row = r_hi - r, T[row][q] = hz[s_q - up r], s_q = (q + n_pre_remove) dn
+    if (e == hipSuccess && d->up <= 16) {
+        const int64_t up = d->up, dn = d->down;
+        const int64_t s0 = (int64_t)d->n_pre_remove * dn, sl = (up - 1 + d->n_pre_remove) * dn;
+        const int64_t r_hi = sl / up, r_lo = s0 / up - (p->J - 1);
+        const int64_t nrows = r_hi - r_lo + 1;
+        const int64_t rpw = ((nrows + FEG_WAVES - 1) / FEG_WAVES + 1) & ~(int64_t)1;   // rows per wavefront, even (two per trip)
+        const int pad = (dn % 2 == 0) ? 1 : 0;
+        const int64_t o_max = FEG_WAVES * rpw - 1;
+        const int64_t span = dn * (FEG_G - 1) + FEG_WAVES * rpw;
+        const int64_t x_elems = span + pad * ((span - 1) / dn) + 1;
+        size_t lds = sizeof(float2) * (size_t)x_elems;
+        const size_t lds_p = sizeof(float2) * FEG_WAVES * (size_t)(up | 1) * FEG_G;
+        if (lds < lds_p) lds = lds_p;
+        if (lds <= 78 * 1024) {                                            // two workgroups per CU
+            std::vector<float> T((size_t)FEG_WAVES * rpw * 16, 0.f);
+            for (int64_t row = 0; row < FEG_WAVES * rpw; ++row) {
+                const int64_t r = r_hi - row;
+                for (int64_t q = 0; q < up; ++q) {
+                    const int64_t idx = (q + d->n_pre_remove) * dn - up * r;
+                    if (idx >= 0 && idx < d->ntaps) T[(size_t)row * 16 + q] = d->taps_host[idx];
+                }
+            }
+            e = hipMalloc(&p->d_T, sizeof(float) * T.size());
+            if (e == hipSuccess) e = hipMemcpy(p->d_T, T.data(), sizeof(float) * T.size(), hipMemcpyHostToDevice);
+            p->g.T = p->d_T;
+            p->g.rows_per_wave = (int32_t)rpw;
+            p->g.r_first = (int32_t)(r_hi - o_max);
+            p->g.lane_stride = (int32_t)(dn + pad);
+            p->g.pad = pad;
+            p->g.span = (int32_t)span;
+            p->g.inv_dn = 1.0f / (float)dn;
+            p->g_lds = lds;
+        }
+    }
     if (e != hipSuccess) {
         prc_set_error("prc_frontend_plan_create: device setup failed: %s", hipGetErrorString(e));
         prc_frontend_plan_destroy(p);
@@ -200,6 +469,28 @@ extern "C" int prc_frontend_execute(prc_frontend_plan* p, const void* raw, int64
     a.pr.rcp32 = 1.0f / (float)fs;
     a.pr.off32 = 0.f;
     a.pr.enabled = a.mix;
+    a.src = p->desc.raw_dtype;
+    a.opw = 0;
+    const int64_t method = prc_opt(PRC_OPT_FE_METHOD);
+    PRC_REQUIRE(method != 2 || p->d_T, PRC_EUNSUPPORTED,
+                "prc_frontend_execute: the group form needs up <= 16 and a window of 64 down samples within 78 KB of LDS (up=%d, down=%d)",
+                a.up, a.dn);
+    if (p->d_T && method != 1) {
+        dim3 grid((unsigned)ceil_div64(p->n_out, (int64_t)FEG_G * a.up), (unsigned)nblocks);
+#define PRC_FEG_CASE(Q)                                                                              \
+    case Q:                                                                                          \
+        if (int rc_ = prc_lds_optin((const void*)frontend_group_kernel<Q>, (int)p->g_lds)) return rc_; \
+        hipLaunchKernelGGL(frontend_group_kernel<Q>, grid, dim3(FEG_THREADS), p->g_lds, stream, a, p->g);    \
+        break;
+        switch (a.up) {
+            PRC_FEG_CASE(1) PRC_FEG_CASE(2) PRC_FEG_CASE(3) PRC_FEG_CASE(4) PRC_FEG_CASE(5) PRC_FEG_CASE(6)
+            PRC_FEG_CASE(7) PRC_FEG_CASE(8) PRC_FEG_CASE(9) PRC_FEG_CASE(10) PRC_FEG_CASE(11) PRC_FEG_CASE(12)
+            PRC_FEG_CASE(13) PRC_FEG_CASE(14) PRC_FEG_CASE(15) PRC_FEG_CASE(16)
+        }
+#undef PRC_FEG_CASE
+        PRC_LAUNCH_CHECK();
+        return PRC_OK;
+    }
     // staged span per workgroup: opw outputs * dn/up inputs + J taps of history; opw shrinks (in steps of one
     // wavefront) until the span fits the CU's LDS, so any decimation ratio runs
     const size_t lds_taps = sizeof(float) * ((size_t)(a.J * a.up + 1) & ~(size_t)1);

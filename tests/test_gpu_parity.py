@@ -978,3 +978,43 @@ def test_caf_team_workgroup_orders_give_the_same_maps(nref):
     b = nf - 2
     exp = O.fast_xambg(refs[-1][b * n // 2:b * n // 2 + n], srv[b * n // 2:b * n // 2 + n], R, F, n, np.kaiser(n, 5.0))
     assert rel_err(results[0][-1][b], exp[:, :, 0]) < TIGHT
+
+
+@pytest.mark.parametrize("up,dn", [(13, 119), (3, 7), (1, 4), (5, 4), (16, 15), (2, 9), (17, 40)])
+def test_front_end_kernel_forms_agree(up, dn):
+    """frontend_group_kernel (`up` outputs per thread, taps through the scalar unit, rows split over four wavefronts)
+    against frontend_kernel (one output per thread) and the oracle: every raw type, tuning on and off, blocks shorter
+    than one window, an even decimation (padded LDS layout), and a ratio the group form does not take (up = 17)."""
+    from passiveradar_amd import _lib, engine
+    from passiveradar_amd.signal_utils import front_end, resample
+    rng = np.random.default_rng(up * 100 + dn)
+    fs, foff = 2_400_000, 100_000
+    old = _lib.get_option(_lib.OPT_FE_METHOD)
+    try:
+        for dt, n_in, nblk in (("int8", 9001, 3), ("int16", 700, 2), ("float32", 64 * dn + 5, 1), ("uint8", 2 * dn + 3, 4)):
+            if dt == "float32":
+                raw = rng.standard_normal(2 * n_in * nblk).astype(np.float32)
+            else:
+                info = np.iinfo(dt)
+                raw = rng.integers(info.min, info.max, 2 * n_in * nblk, endpoint=True).astype(dt)
+            got = {}
+            for method in (1, 2, 0):
+                if method == 2 and up > 16:
+                    _lib.set_option(_lib.OPT_FE_METHOD, 2)
+                    with pytest.raises(RuntimeError):
+                        front_end(raw, 2 * n_in, foff, fs, up, dn, max_blocks=2)
+                    continue
+                _lib.set_option(_lib.OPT_FE_METHOD, method)
+                got[method] = front_end(raw, 2 * n_in, foff, fs, up, dn, max_blocks=2)
+            exp = O.front_end(raw, 2 * n_in, foff, fs, up, dn)
+            for method, y in got.items():
+                assert y.shape == exp.shape and rel_err(y, exp) < TIGHT, (dt, method)
+            if 2 in got:
+                assert rel_err(got[2], got[1]) < 2e-6, dt               # same samples, same taps; the sum is split in four
+                assert np.array_equal(got[0], got[2])                   # the default IS the group form where it applies
+        x = (rng.standard_normal(5000) + 1j * rng.standard_normal(5000)).astype(np.complex64)
+        for method in (1, 0):
+            _lib.set_option(_lib.OPT_FE_METHOD, method)
+            assert rel_err(resample(x, up, dn), O.resample(x, up, dn)) < TIGHT
+    finally:
+        _lib.set_option(_lib.OPT_FE_METHOD, old)

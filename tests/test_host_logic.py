@@ -307,3 +307,35 @@ def test_doppler_column_kernel_phases_on_the_cpu(F):
         assert h.dop_emul(F, y.ctypes.data, out.ctypes.data, cols, nf) == 0
         exp = np.fft.fftshift(np.fft.fft(y.astype(np.complex128), axis=1), axes=1)
         assert np.abs(out - exp).max() / np.abs(exp).max() < 1e-6
+
+
+@pytest.mark.parametrize("up,dn,n", [(13, 119, 20000), (3, 7, 5000), (1, 4, 4001), (5, 4, 3000), (16, 15, 2000), (7, 1, 900)])
+def test_front_end_group_tables_reproduce_the_resampler(up, dn, n):
+    """tools/frontend_group_model.py builds the tap rows, LDS offsets (with the pad sample of an even decimation) and
+    windows of frontend_group_kernel exactly as the plan and the kernel do; replayed in NumPy they must give
+    resample_poly's polyphase sum (the oracle's restatement, itself pinned to the reference's output)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import np_oracle as O
+    from tools import frontend_group_model as M
+    rng = np.random.default_rng(up * 1000 + dn)
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    hp, npr, u, d = O.resample_design(up, dn)
+    ref = O.resample(x, up, dn)
+    slope = (x[-1] - x[0]) / (n - 1)
+
+    def xe(i):
+        i = np.asarray(i)
+        out = np.empty(i.shape, dtype=np.complex128)
+        lo, hi = i < 0, i >= n
+        mid = ~(lo | hi)
+        out[lo] = x[0] + slope * i[lo]
+        out[hi] = x[-1] + slope * (i[hi] - (n - 1))
+        out[mid] = x[i[mid]]
+        return out
+    y = M.run(xe, ref.shape[0], hp, u, d, npr, dtype=np.complex128)
+    assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-7          # the taps are float32 in the table
+    T, roff, rpw, r_first, lane_stride, pad, span = M.tables(hp, u, d, npr)
+    assert pad == (1 if d % 2 == 0 else 0) and lane_stride == d + pad and rpw % 2 == 0
+    # every tap of every phase sits in exactly one row
+    assert np.isclose(T[:, :u].sum(), np.asarray(hp, dtype=np.float32).sum(), rtol=1e-5)
