@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRC_VERSION 401   /* 401: prc_comm_loopback, PRC_OPT_FE_METHOD; 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
+#define PRC_VERSION 401   /* 401: prc_comm_loopback, PRC_OPT_FE_METHOD, PRC_OPT_CFAR_METHOD; 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
                              prc_comm_count; 310: prc_ls_desc.method = 4, NLMS up to 8192 taps */
 
 typedef enum prc_status {
@@ -83,7 +83,9 @@ typedef enum prc_option {
     PRC_OPT_FE_METHOD = 9,        /* front-end kernel, read per launch: 0 (default) = the group form (`up` outputs per thread, taps
                                      through the scalar unit) where it applies (up <= 16, window within LDS), else one output per
                                      thread; 1 = one output per thread; 2 = the group form or PRC_EUNSUPPORTED                */
-    PRC_OPT_COUNT_ = 10
+    PRC_OPT_CFAR_METHOD = 10,     /* prc_cfar2d, read per call: 0 (default) = separable sums (rows, then columns) where the tile fits
+                                     LDS, 1 = every tap of the box per output                                               */
+    PRC_OPT_COUNT_ = 11
 } prc_option;
 int prc_set_option(int32_t option, int64_t value);     /* PRC_EINVAL for an unknown option or a value out of range */
 int prc_get_option(int32_t option, int64_t* value);

@@ -68,6 +68,74 @@ __global__ __launch_bounds__(CF_TX * CF_TY) void cfar_kernel(const float* __rest
     out[(int64_t)f * H * W + (int64_t)i * W + j] = use_thresh ? (cr > thresh ? 1.f : 0.f) : cr;
 }
 
+
+// The same sums, separably (round 4).  The annulus is rows of full width outside the guard rows and two side pieces
+// inside them: per tile row and column the kernel first forms  Ho = sum over the taps outside [e1, e2)  and  Hf = Ho +
+// the taps inside, then an output adds fw of those down its column (Hf, or Ho on a guard row).  2 fw LDS reads per
+// output instead of fw^2 - (gw+1)^2 (36 against 299 at CFAR_2D(18, 4)), no subtraction of a large box from a larger
+// one (a strong cell under test never meets the noise it is compared with in one sum).  Tile 16 x 64 outputs per
+// workgroup; the wrap-around indices are advanced, not divided.
+#define CS_TX 64
+#define CS_TY 16
+__global__ __launch_bounds__(256) void cfar_sep_kernel(const float* __restrict__ X, int H, int W, int fw, int e1, int e2,
+                                                       float inv_cells, const float* __restrict__ partial, int npartial,
+                                                       float thresh, int use_thresh, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int th = CS_TY + fw - 1, tw = CS_TX + fw - 1, twp = tw | 1;
+    float* tile = reinterpret_cast<float*>(smem_raw);        // th x twp
+    float* Ho = tile + th * twp;                             // th x CS_TX
+    float* Hf = Ho + th * CS_TX;
+    const int f = blockIdx.z;
+    const float* x = X + (int64_t)f * H * W;
+    const int c = (fw - 1) / 2;
+    const int i0 = blockIdx.y * CS_TY, j0 = blockIdx.x * CS_TX;
+    const int tx = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    // tile element (r, s) <-> X[(i0 + c - (fw-1) + r) mod H, (j0 + c - (fw-1) + s) mod W]
+    int ii = (i0 + c - (fw - 1) + tq) % H;
+    if (ii < 0) ii += H;
+    const int rstep = 4 % H;
+    for (int r = tq; r < th; r += 4) {
+        int jj = (j0 + c - (fw - 1) + tx) % W;
+        if (jj < 0) jj += W;
+        const int sstep = 64 % W;
+        for (int s_ = tx; s_ < tw; s_ += 64) {
+            tile[r * twp + s_] = x[(int64_t)ii * W + jj];
+            jj += sstep;
+            if (jj >= W) jj -= W;
+        }
+        ii += rstep;
+        if (ii >= H) ii -= H;
+    }
+    float tot = 0.f;
+    for (int k = 0; k < npartial; ++k) tot += partial[(int64_t)f * npartial + k];
+    const float mean_abs = tot / (float)((int64_t)H * W);
+    __syncthreads();
+    for (int r = tq; r < th; r += 4) {
+        const float* row = tile + r * twp + (fw - 1) + tx;   // tap b reads row[-b]
+        float so = 0.f, sm = 0.f;
+        for (int b = 0; b < e1; ++b) so += row[-b];
+        for (int b = e1; b < e2; ++b) sm += row[-b];
+        for (int b = e2; b < fw; ++b) so += row[-b];
+        Ho[r * CS_TX + tx] = so;
+        Hf[r * CS_TX + tx] = so + sm;
+    }
+    __syncthreads();
+    const int j = j0 + tx;
+    if (j >= W) return;
+    for (int ty = tq; ty < CS_TY; ty += 4) {
+        const int i = i0 + ty;
+        if (i >= H) break;
+        float acc = 0.f;
+        const int base = ((fw - 1) + ty) * CS_TX + tx;       // tap a reads [base - a CS_TX]
+        for (int a = 0; a < e1; ++a) acc += Hf[base - a * CS_TX];
+        for (int a = e1; a < e2; ++a) acc += Ho[base - a * CS_TX];
+        for (int a = e2; a < fw; ++a) acc += Hf[base - a * CS_TX];
+        const float xv = tile[((fw - 1) + ty - c) * twp + (fw - 1) + tx - c];
+        const float cr = (xv / mean_abs) / (acc * inv_cells + 1e-10f);
+        out[(int64_t)f * H * W + (int64_t)i * W + j] = use_thresh ? (cr > thresh ? 1.f : 0.f) : cr;
+    }
+}
+
 extern "C" int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int32_t gw, int32_t use_thresh,
                           float thresh, float* out, int32_t nframes, void* stream_) {
     PRC_REQUIRE(X && out, PRC_EINVAL, "prc_cfar2d: null argument");
@@ -124,11 +192,20 @@ extern "C" int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int3
     int e1 = (fw - gw) / 2, e2 = fw - e1 + 1;
     if (e1 < 0) e1 = 0;
     if (e2 > fw) e2 = fw;
-    const size_t lds = sizeof(float) * (size_t)(CF_TY + fw - 1) * (CF_TX + fw - 1);
-    PRC_REQUIRE(lds <= 64 * 1024, PRC_EUNSUPPORTED, "prc_cfar2d: kernel width %d too large", fw);
-    dim3 grid((W + CF_TX - 1) / CF_TX, (H + CF_TY - 1) / CF_TY, nframes);
-    hipLaunchKernelGGL(cfar_kernel, grid, dim3(CF_TX * CF_TY), lds, stream, X, H, W, fw, e1, e2,
-                       1.0f / (float)(fw * fw - gw * gw), d_partial, np, thresh, use_thresh, out);
+    const float inv_cells = 1.0f / (float)(fw * fw - gw * gw);
+    const size_t th = (size_t)CS_TY + fw - 1, twp = ((size_t)CS_TX + fw - 1) | 1;
+    const size_t lds_sep = sizeof(float) * (th * twp + 2 * th * CS_TX);
+    if (lds_sep <= 64 * 1024 && prc_opt(PRC_OPT_CFAR_METHOD) != 1) {
+        dim3 grid((W + CS_TX - 1) / CS_TX, (H + CS_TY - 1) / CS_TY, nframes);
+        hipLaunchKernelGGL(cfar_sep_kernel, grid, dim3(256), lds_sep, stream, X, H, W, fw, e1, e2, inv_cells, d_partial, np,
+                           thresh, use_thresh, out);
+    } else {
+        const size_t lds = sizeof(float) * (size_t)(CF_TY + fw - 1) * (CF_TX + fw - 1);
+        PRC_REQUIRE(lds <= 64 * 1024, PRC_EUNSUPPORTED, "prc_cfar2d: kernel width %d too large", fw);
+        dim3 grid((W + CF_TX - 1) / CF_TX, (H + CF_TY - 1) / CF_TY, nframes);
+        hipLaunchKernelGGL(cfar_kernel, grid, dim3(CF_TX * CF_TY), lds, stream, X, H, W, fw, e1, e2, inv_cells, d_partial, np,
+                           thresh, use_thresh, out);
+    }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { prc_set_error("prc_cfar2d: launch failed: %s", hipGetErrorString(le)); return PRC_EHIP; }
     return PRC_OK;

@@ -1018,3 +1018,36 @@ def test_front_end_kernel_forms_agree(up, dn):
             assert rel_err(resample(x, up, dn), O.resample(x, up, dn)) < TIGHT
     finally:
         _lib.set_option(_lib.OPT_FE_METHOD, old)
+
+
+@pytest.mark.parametrize("H,W,fw,gw", [(1024, 177, 18, 4), (64, 257, 18, 4), (5, 7, 18, 4), (33, 64, 7, 2), (40, 130, 9, 0),
+                                       (16, 65, 8, 3), (3, 200, 5, 1), (100, 3, 6, 2), (70, 90, 31, 11)])
+def test_cfar_kernel_forms_agree(H, W, fw, gw):
+    """cfar_sep_kernel (row sums, then column sums: 2 fw LDS reads per cell) against cfar_kernel (every tap of the box
+    per cell) and the oracle's convolve2d restatement: maps smaller than the box (wrap-around more than once), odd and
+    even widths (the reference's asymmetric centring), no guard cells, several frames, ratio and threshold outputs."""
+    import torch
+    from passiveradar_amd import _lib
+    from passiveradar_amd.target_detection import CFAR_2D
+    rng = np.random.default_rng(H * 1000 + W)
+    X = np.abs(rng.standard_normal((3, H, W)) + 1j * rng.standard_normal((3, H, W))).astype(np.float32)
+    X[1, H // 2, W // 3] += 1e3                                   # a strong cell: the box next to it must not lose the noise
+    old = _lib.get_option(_lib.OPT_CFAR_METHOD)
+    try:
+        got = {}
+        for method in (1, 0):
+            _lib.set_option(_lib.OPT_CFAR_METHOD, method)
+            got[method] = CFAR_2D(torch.from_numpy(X).cuda(), fw, gw).cpu().numpy()
+        for k in range(3):
+            exp = O.CFAR_2D(X[k], fw, gw)
+            for method in (0, 1):
+                assert rel_err(got[method][k], exp) < TIGHT, (method, k)
+        assert rel_err(got[0], got[1]) < 2e-6
+        thr = float(np.median(got[1]))
+        det = {}
+        for method in (1, 0):
+            _lib.set_option(_lib.OPT_CFAR_METHOD, method)
+            det[method] = CFAR_2D(torch.from_numpy(X).cuda(), fw, gw, thr).cpu().numpy()
+        assert (det[0] != det[1]).mean() < 1e-3                   # cells within a rounding of the threshold may flip
+    finally:
+        _lib.set_option(_lib.OPT_CFAR_METHOD, old)
