@@ -250,6 +250,34 @@ def save_range_doppler(config, frames):
     raise ValueError("Unsupported output file type. Enter 'hdf5' or 'zarr'")
 
 
+class ZarrFrameWriter:
+    """The zarr v2 store of main.py:216-224, (F, R+1, nframes) complex64 in chunks (F, R+1, 1), written frame by frame:
+    chunk '0.0.i' IS frame i in C order, so frames can be stored in any order and as they arrive (the reference's
+    dask graph stores chunk by chunk as well); nothing is transposed in host memory."""
+
+    def __init__(self, path, F, cols, nframes):
+        self.path, self.F, self.cols, self.nframes = path, int(F), int(cols), int(nframes)
+        os.makedirs(path, exist_ok=True)
+        # what zarr.open(mode='w', shape=..., chunks=(F, R+1, 1), dtype=complex64) of main.py:216-221 records, except for
+        # the compressor (zarr's default is Blosc; null = raw chunks, which every v2 reader accepts)
+        meta = {"zarr_format": 2, "shape": [self.F, self.cols, self.nframes], "chunks": [self.F, self.cols, 1], "dtype": "<c8",
+                "compressor": None, "fill_value": [0.0, 0.0], "order": "C", "filters": None}
+        validate_zarr_v2_metadata(meta)
+        with open(os.path.join(path, ".zarray"), "w") as fh:
+            json.dump(meta, fh, indent=1)
+        with open(os.path.join(path, ".zattrs"), "w") as fh:
+            fh.write("{}")
+
+    def write(self, first, frames):
+        """frames: [m][F][R+1] complex64 (NumPy) = frames first .. first + m - 1 of the stream"""
+        frames = np.asarray(frames)
+        if frames.dtype != np.complex64 or frames.shape[1:] != (self.F, self.cols) or first < 0 or first + frames.shape[0] > self.nframes:
+            raise ValueError(f"ZarrFrameWriter.write: block {frames.shape} {frames.dtype} at frame {first} does not fit "
+                             f"({self.nframes}, {self.F}, {self.cols}) complex64")
+        for k in range(frames.shape[0]):
+            np.ascontiguousarray(frames[k]).tofile(os.path.join(self.path, f"0.0.{first + k}"))
+
+
 def save_range_doppler_zarr(path, frames):
     """frames: [nframes][F][R+1] complex64 (NumPy array or torch tensor) -> zarr v2 store at ``path``
     holding the (F, R+1, nframes) array of main.py:216-224."""
@@ -257,18 +285,7 @@ def save_range_doppler_zarr(path, frames):
         frames = frames.cpu().numpy()
     frames = np.ascontiguousarray(frames, dtype=np.complex64)
     nframes, F, cols = frames.shape
-    os.makedirs(path, exist_ok=True)
-    # what zarr.open(mode='w', shape=..., chunks=(F, R+1, 1), dtype=complex64) of main.py:216-221 records, except for
-    # the compressor (zarr's default is Blosc; null = raw chunks, which every v2 reader accepts)
-    meta = {"zarr_format": 2, "shape": [F, cols, nframes], "chunks": [F, cols, 1], "dtype": "<c8",
-            "compressor": None, "fill_value": [0.0, 0.0], "order": "C", "filters": None}
-    validate_zarr_v2_metadata(meta)
-    with open(os.path.join(path, ".zarray"), "w") as fh:
-        json.dump(meta, fh, indent=1)
-    with open(os.path.join(path, ".zattrs"), "w") as fh:
-        fh.write("{}")
-    for i in range(nframes):
-        frames[i].tofile(os.path.join(path, f"0.0.{i}"))       # chunk (F, R+1, 1) == frame i, C order
+    ZarrFrameWriter(path, F, cols, nframes).write(0, frames)
     return path
 
 

@@ -339,3 +339,21 @@ def test_front_end_group_tables_reproduce_the_resampler(up, dn, n):
     assert pad == (1 if d % 2 == 0 else 0) and lane_stride == d + pad and rpw % 2 == 0
     # every tap of every phase sits in exactly one row
     assert np.isclose(T[:, :u].sum(), np.asarray(hp, dtype=np.float32).sum(), rtol=1e-5)
+
+
+def test_zarr_frame_writer_stores_blocks_in_any_order(tmp_path):
+    """ZarrFrameWriter (the store bench.py --workload prconfig fills batch by batch from a host thread) writes the same
+    store as save_range_doppler_zarr whatever the order of the blocks, and refuses a block that does not fit."""
+    from passiveradar_amd import output
+    rng = np.random.default_rng(3)
+    frames = (rng.standard_normal((7, 6, 5)) + 1j * rng.standard_normal((7, 6, 5))).astype(np.complex64)
+    a, b = str(tmp_path / "a.zarr"), str(tmp_path / "b.zarr")
+    output.save_range_doppler_zarr(a, frames)
+    w = output.ZarrFrameWriter(b, 6, 5, 7)
+    for lo, hi in ((4, 7), (0, 1), (1, 4)):
+        w.write(lo, frames[lo:hi])
+    got, exp = output.read_zarr_v2(b), output.read_zarr_v2(a)
+    assert got.shape == (6, 5, 7) and np.array_equal(got, exp) and np.array_equal(got, np.moveaxis(frames, 0, 2))
+    for bad_first, blk in ((5, frames[:3]), (-1, frames[:1]), (0, frames[:1].astype(np.complex128)), (0, frames[:1, :5])):
+        with pytest.raises(ValueError):
+            w.write(bad_first, blk)
