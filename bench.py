@@ -284,18 +284,23 @@ def prconfig_main(args):
             zw = output.ZarrFrameWriter(c2["range_doppler_map_fname"], F, R + 1, nchunks)
             maps_np = maps_h.numpy()
             q = queue.Queue()
-            busy = [0.0]
+            busy, failed = [0.0], []
 
             def drain_store():
                 while True:
                     item = q.get()
                     if item is None:
                         return
-                    landed_, lo_, hi_ = item
-                    landed_.synchronize()
-                    t2 = time.perf_counter()
-                    zw.write(lo_, maps_np[lo_:hi_])
-                    busy[0] += time.perf_counter() - t2
+                    if failed:
+                        continue                                  # keep draining so that the producer never blocks
+                    try:
+                        landed_, lo_, hi_ = item
+                        landed_.synchronize()
+                        t2 = time.perf_counter()
+                        zw.write(lo_, maps_np[lo_:hi_])
+                        busy[0] += time.perf_counter() - t2
+                    except Exception as e:                        # noqa: BLE001 -- re-raised on the main thread after the join
+                        failed.append(e)
             writer = threading.Thread(target=drain_store)
             writer.start()
         for k, b0 in enumerate(range(0, nchunks, nbat)):
@@ -339,6 +344,8 @@ def prconfig_main(args):
         if store:
             q.put(None)
             writer.join()
+            if failed:
+                raise failed[0]
             marks["store_s"] = busy[0]
             marks["store_wall_s"] = time.perf_counter() - t1
 
