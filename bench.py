@@ -41,6 +41,9 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's (and torch's) buffer sharing between the
+# ranks of a node fails with "hipIpcGetMemHandle: invalid argument".  Already exported on the boxes; kept for any other env.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector peak
