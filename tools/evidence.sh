@@ -58,6 +58,8 @@ run caf_longfir_direct python3 $R/tools/caf_bench.py --shape cfg2 --frames 16 --
 # multi-illuminator modes on one box
 for m in turns shared pairs; do run caf_multi_cfg5_$m python3 $R/tools/caf_bench.py --shape cfg5 --frames 16 --nref 4 --multi $m; done
 for m in turns shared; do run caf_multi_cfg3_$m python3 $R/tools/caf_bench.py --shape cfg3 --frames 32 --nref 4 --multi $m; done
+# the rows either side of the path: front end and CFAR kernels alone (both forms of each)
+(cd $R && run fe_bench python3 tools/frontend_bench.py && run cfar_bench python3 tools/cfar_bench.py)
 # 2. kernel traces: the default pipeline (overlapped streams) and the same kernels back to back on one stream
 trace trace_cfg2 --no-cpu --frames 1024 --steps 5 --warmup 1
 trace trace_cfg2_serial --no-cpu --frames 1024 --steps 5 --warmup 1 --no-overlap
