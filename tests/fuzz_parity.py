@@ -132,11 +132,27 @@ def worker(wseed):
           up, dn = int(rng.integers(1, 20)), int(rng.integers(1, 130))
           e1 = rel(resample(x, up, dn), O.resample(x, up, dn))
           fc = float(rng.uniform(-2e5, 2e5)); e2 = rel(frequency_shift(x, fc, 2.4e6, 0.3), O.frequency_shift(x, fc, 2.4e6, 0.3))
-          note("front_end", max(e1, e2, 0.0 if ok else 1.0), 2e-5, ("fe", n, dt, up, dn, fc))
+          # the fused chain on raw blocks (deinterleave -> block-phase tuning -> resample), either kernel form
+          from math import gcd
+          from passiveradar_amd import _lib
+          nb = int(rng.integers(1, 4)); n_in = max(n // nb // 2, 2 * dn + 3); foff = int(rng.choice([100000, 37500, 2400]))
+          rawb = (rng.standard_normal(2 * n_in * nb) * 30).astype(dt)
+          _lib.set_option(_lib.OPT_FE_METHOD, int(rng.integers(0, 2)))
+          try:
+              e3 = rel(front_end(rawb, 2 * n_in, foff, 2400000, up, dn, max_blocks=2), O.front_end(rawb, 2 * n_in, foff, 2400000, up, dn)) \
+                  if up // gcd(up, dn) != dn // gcd(up, dn) else 0.0
+          finally:
+              _lib.set_option(_lib.OPT_FE_METHOD, 0)
+          note("front_end", max(e1, e2, e3, 0.0 if ok else 1.0), 2e-5, ("fe", n, dt, up, dn, fc, nb, foff))
       elif k == 9:    # CFAR
           H, W = int(rng.integers(20, 300)), int(rng.integers(20, 300)); fw = int(rng.integers(3, 19)); gw = int(rng.integers(0, fw - 1))
           X = np.abs(rng.standard_normal((H, W))).astype(np.float32) + 0.1
-          note("cfar", rel(CFAR_2D(X, fw, gw), O.CFAR_2D(X, fw, gw)), 2e-5, ("cfar", H, W, fw, gw))
+          from passiveradar_amd import _lib
+          _lib.set_option(_lib.OPT_CFAR_METHOD, int(rng.integers(0, 2)))
+          try:
+              note("cfar", rel(CFAR_2D(X, fw, gw), O.CFAR_2D(X, fw, gw)), 2e-5, ("cfar", H, W, fw, gw))
+          finally:
+              _lib.set_option(_lib.OPT_CFAR_METHOD, 0)
       elif k == 10:   # zero-phase IIR decimator
           n = int(rng.integers(28, 60000)); q = int(rng.choice([1, 2, 3, 4, 5, 8, 10]))
           x = scene.white_reference(n, int(rng.integers(1 << 30)))
