@@ -980,11 +980,12 @@ def test_caf_team_workgroup_orders_give_the_same_maps(nref):
     assert rel_err(results[0][-1][b], exp[:, :, 0]) < TIGHT
 
 
-@pytest.mark.parametrize("up,dn", [(13, 119), (3, 7), (1, 4), (5, 4), (16, 15), (2, 9), (17, 40)])
+@pytest.mark.parametrize("up,dn", [(13, 119), (3, 7), (1, 4), (5, 4), (16, 15), (2, 9), (17, 40), (3, 170)])
 def test_front_end_kernel_forms_agree(up, dn):
     """frontend_group_kernel (`up` outputs per thread, taps through the scalar unit, rows split over four wavefronts)
     against frontend_kernel (one output per thread) and the oracle: every raw type, tuning on and off, blocks shorter
-    than one window, an even decimation (padded LDS layout), and a ratio the group form does not take (up = 17)."""
+    than one window, an even decimation (padded LDS layout), and two ratios the group form does not take (up = 17; a
+    window of 64 x 170 samples, more than two workgroups per CU can hold): AUTO falls back, an explicit request is refused."""
     from passiveradar_amd import _lib, engine
     from passiveradar_amd.signal_utils import front_end, resample
     rng = np.random.default_rng(up * 100 + dn)
@@ -999,7 +1000,7 @@ def test_front_end_kernel_forms_agree(up, dn):
                 raw = rng.integers(info.min, info.max, 2 * n_in * nblk, endpoint=True).astype(dt)
             got = {}
             for method in (1, 2, 0):
-                if method == 2 and up > 16:
+                if method == 2 and (up > 16 or dn >= 150):
                     _lib.set_option(_lib.OPT_FE_METHOD, 2)
                     with pytest.raises(RuntimeError):
                         front_end(raw, 2 * n_in, foff, fs, up, dn, max_blocks=2)
