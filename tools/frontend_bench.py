@@ -24,9 +24,9 @@ for method in methods:
     dt = e0.elapsed_time(e1) * 1e-3 / 5
     outs[method] = out.clone()
     nout = out.shape[0] // nblk
-    gflop = nblk * nout * 8.0 * 2381 / 13 / 1e9           # real-tap x complex-sample multiply-adds of the polyphase sum
+    gflop = nblk * (nout * 4.0 * 2381 / 13 + (icl // 2) * 6.0) / 1e9   # real tap x complex sample multiply-adds on non-zero taps + one rotation product per input
     print(f"front end method {method}: {nblk} blocks in {dt*1e3:.3f} ms -> {dt/nblk*1e6:.2f} us per block-channel "
-          f"({icl*nblk/dt/1e9:.1f} GB/s raw in, {(icl + 8*nout)*nblk/dt/1e12:.3f} TB/s in+out, {gflop/dt/1e3:.1f} TFLOP/s of FIR)")
+          f"({icl*nblk/dt/1e9:.1f} GB/s raw in, {(icl + 8*nout)*nblk/dt/1e12:.3f} TB/s in+out, {gflop/dt/1e3:.1f} TFLOP/s of FIR + rotation products)")
 _lib.set_option(_lib.OPT_FE_METHOD, 0)
 if 1 in outs and 2 in outs:
     d = (outs[1] - outs[2]).abs().max().item() / outs[1].abs().max().item()
