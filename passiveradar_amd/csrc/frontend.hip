@@ -95,8 +95,9 @@ __device__ __forceinline__ v2f fe_sincos(double x) {     // (cos x, sin x)
 
 // tuned sample i of the block (reference: complex128 after the array phase offset; rounded to float32 here, the
 // type the resampler's FIR runs in)
+template <int MIX = -1>     // 1: rotate, 0: do not, -1: a.mix decides (a wave-uniform branch per sample)
 __device__ __forceinline__ float2 fe_rotate(const FeArgs& a, float2 v, int64_t i, double blk_phase) {
-    if (!a.mix) return v;
+    if (MIX == 0 || (MIX < 0 && !a.mix)) return v;
     const float ph32 = (a.pr.a32 * (float)(int)i) * a.pr.rcp32;  // float32 ramp, as the reference (n_in < 2^31: plan creation)
     const v2f t = fe_sincos((double)ph32 + blk_phase), x = v2f{v.x, v.y};
     v2f p, d;                                                    // x t = (x.x t.x - x.y t.y, x.y t.x + x.x t.y)
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FeArgs a) {
 // whole 128-byte lines.
 // Inputs are staged tuned, as above.  dn even: a lane stride of dn complex samples would hit dn/gcd banks only; the
 // window is stored with one pad sample per dn.
+typedef float __attribute__((address_space(4))) fe_const_float;
 #define FEG_G 64
 #ifndef FEG_WAVES
 #define FEG_WAVES 8        // wavefronts per workgroup: they share one window and split its rows
@@ -213,48 +215,86 @@ struct FegArgs {
 #ifndef FEG_CHUNK
 #define FEG_CHUNK 8      // raw samples a thread has in flight before it starts rotating them
 #endif
+template <int PAD = -1>     // 1: one pad sample per dn, 0: none, -1: g.pad decides
 __device__ __forceinline__ int feg_at(const FeArgs& a, const FegArgs& g, int k) {
-    if (!g.pad) return k;
+    if (PAD == 0 || (PAD < 0 && !g.pad)) return k;
     int nk = (int)((float)k * g.inv_dn);
     if (nk * a.dn > k) --nk;
     if ((nk + 1) * a.dn <= k) ++nk;
     return k + nk;
 }
-template <int SRC, bool EDGE>
-__device__ __forceinline__ void feg_stage(const FeArgs& a, const FegArgs& g, float2* X, const void* raw, int64_t i_w,
-                                          double blk_phase, int tid) {
-    // FEG_CHUNK loads per thread are issued before the first rotation (a load-rotate-store chain per sample leaves the
-    // wavefront waiting on HBM once per sample).  Indices are clamped, not predicated: straight-line code, and at a
-    // block end (EDGE: two workgroups per block) the clamped sample is replaced by the 'line' extension afterwards.
+// Staging of one window.  FEG_CHUNK loads per thread are issued before the first rotation (a load-rotate-store chain per
+// sample leaves the wavefront waiting on HBM once per sample).  The interior windows of a block -- all but two -- run
+// straight-line code specialised on the sample type, the pad layout and whether the block is tuned: whole trips of
+// FEG_CHUNK samples without a branch, so the compiler interleaves the eight rotation chains; the last, partial trip and
+// the two windows that touch a block end (the 'line' extension) take the general form below (clamped indices, every
+// choice a wave-uniform branch).
+template <int SRC>
+__device__ __forceinline__ void feg_stage_general(const FeArgs& a, const FegArgs& g, float2* X, const void* raw, int64_t i_w,
+                                                  double blk_phase, int k_first, bool edge) {
     FeLine line;
-    if (EDGE) line = fe_line<SRC>(a, raw, blk_phase);
+    if (edge) line = fe_line<SRC>(a, raw, blk_phase);
     const int last = g.span - 1;
-    for (int k0 = tid; k0 < g.span; k0 += FEG_THREADS * FEG_CHUNK) {
+    for (int k0 = k_first; k0 <= last; k0 += FEG_THREADS * FEG_CHUNK) {
         float2 v[FEG_CHUNK];
 #pragma unroll
         for (int c = 0; c < FEG_CHUNK; ++c) {
             int64_t i = i_w + min(k0 + c * FEG_THREADS, last);
-            if (EDGE) i = i < 0 ? 0 : (i >= a.n_in ? a.n_in - 1 : i);
+            if (edge) i = i < 0 ? 0 : (i >= a.n_in ? a.n_in - 1 : i);
             v[c] = fe_load<SRC>(raw, i, a.src);
         }
 #pragma unroll
         for (int c = 0; c < FEG_CHUNK; ++c) {
             const int k = k0 + c * FEG_THREADS;
             const int64_t i = i_w + k;
-#ifdef FEG_EXP_NOROT                  // timing ablation, never shipped: the staging without its rotations
-            float2 t = v[c];
-#else
-            float2 t = fe_rotate(a, v[c], i, blk_phase);
-#endif
-            if (EDGE) {
+            float2 t = fe_rotate<-1>(a, v[c], i, blk_phase);
+            if (edge) {
                 if (i < 0) t = make_float2((float)(line.x0.x + (double)i * line.slope.x), (float)(line.x0.y + (double)i * line.slope.y));
                 else if (i >= a.n_in) {
                     const double d = (double)(i - (a.n_in - 1));
                     t = make_float2((float)(line.xl.x + d * line.slope.x), (float)(line.xl.y + d * line.slope.y));
                 }
             }
-            if (k <= last) X[feg_at(a, g, k)] = t;
+            if (k <= last) X[feg_at<-1>(a, g, k)] = t;
         }
+    }
+}
+template <int SRC, int PAD, int MIX>
+__device__ __forceinline__ void feg_stage_interior(const FeArgs& a, const FegArgs& g, float2* X, const void* raw, int64_t i_w,
+                                                   double blk_phase, int tid) {
+    // whole trips: the same number for every thread (a per-thread bound lets the first lanes of the workgroup take one trip
+    // more than the rest: two of its wavefronts then run both forms, and everybody waits for them at the barrier)
+    const int nfull = g.span / (FEG_THREADS * FEG_CHUNK);
+    int k0 = tid;
+    for (int trip = 0; trip < nfull; ++trip, k0 += FEG_THREADS * FEG_CHUNK) {
+        float2 v[FEG_CHUNK];
+#pragma unroll
+        for (int c = 0; c < FEG_CHUNK; ++c) v[c] = fe_load<SRC>(raw, i_w + k0 + c * FEG_THREADS, a.src);
+        // the loads first, then everything that does not need them (the phases: most of the work) while they are in flight --
+        // left alone the scheduler sinks the loads below the phase arithmetic
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < FEG_CHUNK; ++c) {
+            const int k = k0 + c * FEG_THREADS;
+#ifdef FEG_EXP_NOROT                  // timing ablation, never shipped: the staging without its rotations
+            X[feg_at<PAD>(a, g, k)] = v[c];
+#else
+            X[feg_at<PAD>(a, g, k)] = fe_rotate<MIX>(a, v[c], i_w + k, blk_phase);
+#endif
+        }
+    }
+    feg_stage_general<SRC>(a, g, X, raw, i_w, blk_phase, k0, false);
+}
+template <int SRC>
+__device__ __forceinline__ void feg_stage(const FeArgs& a, const FegArgs& g, float2* X, const void* raw, int64_t i_w,
+                                          double blk_phase, int tid) {
+    if (i_w < 0 || i_w + g.span > a.n_in) feg_stage_general<SRC>(a, g, X, raw, i_w, blk_phase, tid, true);
+    else if (g.pad) {
+        if (a.mix) feg_stage_interior<SRC, 1, 1>(a, g, X, raw, i_w, blk_phase, tid);
+        else feg_stage_interior<SRC, 1, 0>(a, g, X, raw, i_w, blk_phase, tid);
+    } else {
+        if (a.mix) feg_stage_interior<SRC, 0, 1>(a, g, X, raw, i_w, blk_phase, tid);
+        else feg_stage_interior<SRC, 0, 0>(a, g, X, raw, i_w, blk_phase, tid);
     }
 }
 
@@ -270,21 +310,13 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
     const double blk_phase = (a.mix && a.phases) ? a.phases[b] : 0.0;
     const int64_t N0 = (int64_t)blockIdx.x * FEG_G;                 // first group of the workgroup
     const int64_t i_w = N0 * a.dn + g.r_first;                      // input index of the window's first sample
-    // staging: as many instructions as the FIR (one rotation per input sample), so the loop is specialised outside --
-    // by sample type, and by whether the window touches a block end (the 'line' extension) -- not per sample
-    const bool inside = i_w >= 0 && i_w + g.span <= a.n_in;
-#define FEG_STAGE(S)                                                                                         \
-    case S:                                                                                                  \
-        if (inside) feg_stage<S, false>(a, g, X, raw, i_w, blk_phase, tid);                                  \
-        else feg_stage<S, true>(a, g, X, raw, i_w, blk_phase, tid);                                          \
-        break;
-    switch (a.src) {
-        FEG_STAGE(PRC_RAW_I8) FEG_STAGE(PRC_RAW_U8) FEG_STAGE(PRC_RAW_I16) FEG_STAGE(PRC_RAW_F32)
-        default:
-            if (inside) feg_stage<PRC_RAW_C64, false>(a, g, X, raw, i_w, blk_phase, tid);
-            else feg_stage<PRC_RAW_C64, true>(a, g, X, raw, i_w, blk_phase, tid);
+    switch (a.src) {            // one scalar branch per window, not per sample
+        case PRC_RAW_I8: feg_stage<PRC_RAW_I8>(a, g, X, raw, i_w, blk_phase, tid); break;
+        case PRC_RAW_U8: feg_stage<PRC_RAW_U8>(a, g, X, raw, i_w, blk_phase, tid); break;
+        case PRC_RAW_I16: feg_stage<PRC_RAW_I16>(a, g, X, raw, i_w, blk_phase, tid); break;
+        case PRC_RAW_F32: feg_stage<PRC_RAW_F32>(a, g, X, raw, i_w, blk_phase, tid); break;
+        default: feg_stage<PRC_RAW_C64>(a, g, X, raw, i_w, blk_phase, tid);
     }
-#undef FEG_STAGE
     __syncthreads();
     v2f acc[NQ];
 #pragma unroll
@@ -302,7 +334,11 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
 #pragma unroll 1
     for (int rr = 0; rr < g.rows_per_wave; rr += 2) {
 #endif
-        const float* __restrict__ tr = g.T + (size_t)(row0 + rr) * 16;         // wave-uniform
+        // wave-uniform address in the CONSTANT address space: the rows must come through the scalar unit (s_load into
+        // SGPRs, the taps then ride as scalar operands of the packed multiply-adds).  Through a plain global pointer the
+        // compiler only does that while it can prove that nothing in the kernel writes the table, gives up on a kernel
+        // this size, and loads the 32 taps per trip with vector loads into VGPRs instead (measured: 8.4 -> 12.7 us per block)
+        const fe_const_float* tr = (const fe_const_float*)(g.T + (size_t)(row0 + rr) * 16);
         const int off0 = o + (g.pad ? od : 0);
         --o;
         if (--om < 0) {
@@ -327,7 +363,7 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
     // conflict-free for an odd pitch) and read back as what they are, consecutive outputs ([wave][q][lane] measured 68 %
     // of all LDS cycles of the kernel as bank conflicts: thirteen lanes of a read on one bank)
     float2* P = reinterpret_cast<float2*>(smem_raw);
-    const int pitch = a.up | 1;
+    constexpr int pitch = NQ | 1;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) P[(w * FEG_G + lane) * pitch + q] = make_float2(acc[q].x, acc[q].y);
     __syncthreads();
@@ -400,7 +436,8 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
         const int64_t span = dn * (FEG_G - 1) + FEG_WAVES * rpw;
         const int64_t x_elems = span + pad * ((span - 1) / dn) + 1;
         size_t lds = sizeof(float2) * (size_t)x_elems;
-        const size_t lds_p = sizeof(float2) * FEG_WAVES * (size_t)(up | 1) * FEG_G;
+        const int64_t nq = up <= 4 ? 4 : (up <= 8 ? 8 : (up <= 13 ? 13 : 16));      // accumulators per thread (the kernel's NQ)
+        const size_t lds_p = sizeof(float2) * FEG_WAVES * (size_t)(nq | 1) * FEG_G;
         if (lds < lds_p) lds = lds_p;
         if (lds <= 78 * 1024) {                                            // two workgroups per CU
             std::vector<float> T((size_t)FEG_WAVES * rpw * 16, 0.f);
@@ -482,10 +519,9 @@ extern "C" int prc_frontend_execute(prc_frontend_plan* p, const void* raw, int64
         if (int rc_ = prc_lds_optin((const void*)frontend_group_kernel<Q>, (int)p->g_lds)) return rc_; \
         hipLaunchKernelGGL(frontend_group_kernel<Q>, grid, dim3(FEG_THREADS), p->g_lds, stream, a, p->g);    \
         break;
-        switch (a.up) {
-            PRC_FEG_CASE(1) PRC_FEG_CASE(2) PRC_FEG_CASE(3) PRC_FEG_CASE(4) PRC_FEG_CASE(5) PRC_FEG_CASE(6)
-            PRC_FEG_CASE(7) PRC_FEG_CASE(8) PRC_FEG_CASE(9) PRC_FEG_CASE(10) PRC_FEG_CASE(11) PRC_FEG_CASE(12)
-            PRC_FEG_CASE(13) PRC_FEG_CASE(14) PRC_FEG_CASE(15) PRC_FEG_CASE(16)
+        // accumulators per thread: the smallest of 4, 8, 13, 16 that holds `up` (the tap rows are zero beyond `up`)
+        switch (a.up <= 4 ? 4 : (a.up <= 8 ? 8 : (a.up <= 13 ? 13 : 16))) {
+            PRC_FEG_CASE(4) PRC_FEG_CASE(8) PRC_FEG_CASE(13) PRC_FEG_CASE(16)
         }
 #undef PRC_FEG_CASE
         PRC_LAUNCH_CHECK();
