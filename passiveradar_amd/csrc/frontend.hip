@@ -8,10 +8,15 @@
 //   y[m] = sum_j h[(t mod up) + up j] xe[t div up - j],   t = (m + n_pre_remove) dn,
 // h = firwin(20 max(up,dn)+1, 1/max(up,dn), ('kaiser',5.0)) * up, zero-padded in front (host side,
 // scipy), xe = the tuned block extended linearly through its first and last sample (upfirdn 'line').
-// Tuning keeps the reference's arithmetic: the phase ramp is float32 (sample index held as
-// complex64), the block phase is added and the exponential taken in double (array phase_offset
-// promotes to complex128) -- at 100 kHz offset the float32 ramp is quantised to 1/16 rad, so this
-// has to be reproduced, not improved.
+// Tuning keeps the reference's arithmetic where it is observable: the phase ramp is float32 (sample index
+// held as complex64) and the block phase is added in double (array phase_offset promotes to complex128)
+// -- at 100 kHz offset the float32 ramp is quantised to 1/16 rad, so this has to be reproduced, not
+// improved.  The exponential of that double phase is taken to float32 accuracy (fe_sincos below): the
+// tuned samples enter a float32 FIR either way.
+//
+// Two kernels: frontend_group_kernel (round 4: `up` consecutive outputs per thread; what runs for up <= 16
+// when 64 x down input samples + the filter rows fit LDS twice per CU) and frontend_kernel (one output per
+// thread: any other ratio).  PRC_OPT_FE_METHOD chooses for A/B runs.
 #include "common.h"
 #include <math.h>
 #include <vector>
@@ -31,22 +36,14 @@ struct FeArgs {
     int32_t up, dn, J, n_pre_remove;
     int32_t mix;              // apply the frequency shift
     int32_t opw;              // outputs per workgroup (<= FE_THREADS; fewer when the decimation ratio is large)
-    int32_t src;              // prc_raw_dtype, for the kernels that take it at run time (SRC = FE_SRC_RT)
+    int32_t src;              // prc_raw_dtype, for the group kernel (it branches on the type once per window)
     PhaseRamp pr;
 };
-#define FE_SRC_RT 99
+#define FE_SRC_RT 99      // fe_block<FE_SRC_RT>: the block's base address from FeArgs.src
 
 template <int SRC>
-__device__ __forceinline__ float2 fe_load(const void* raw, int64_t i, int src = 0) {
-    if (SRC == FE_SRC_RT) {                 // the type is a (wave-uniform) kernel argument: one scalar branch per sample
-        switch (src) {
-            case PRC_RAW_I8: return fe_load<PRC_RAW_I8>(raw, i);
-            case PRC_RAW_U8: return fe_load<PRC_RAW_U8>(raw, i);
-            case PRC_RAW_I16: return fe_load<PRC_RAW_I16>(raw, i);
-            case PRC_RAW_F32: return fe_load<PRC_RAW_F32>(raw, i);
-            default: return fe_load<PRC_RAW_C64>(raw, i);
-        }
-    } else if (SRC == PRC_RAW_I8) {
+__device__ __forceinline__ float2 fe_load(const void* raw, int64_t i) {
+    if (SRC == PRC_RAW_I8) {
         const signed char* p = (const signed char*)raw;
         return make_float2((float)p[2 * i], (float)p[2 * i + 1]);
     } else if (SRC == PRC_RAW_U8) {
@@ -107,7 +104,7 @@ __device__ __forceinline__ float2 fe_rotate(const FeArgs& a, float2 v, int64_t i
 }
 template <int SRC>
 __device__ __forceinline__ float2 fe_tuned(const FeArgs& a, const void* raw, int64_t i, double blk_phase) {
-    return fe_rotate(a, fe_load<SRC>(raw, i, a.src), i, blk_phase);
+    return fe_rotate(a, fe_load<SRC>(raw, i), i, blk_phase);
 }
 
 // 'line' extension of upfirdn: xe[i] = x[0] + i*slope (i < 0),  x[n-1] + (i-(n-1))*slope (i >= n)
@@ -241,7 +238,7 @@ __device__ __forceinline__ void feg_stage_general(const FeArgs& a, const FegArgs
         for (int c = 0; c < FEG_CHUNK; ++c) {
             int64_t i = i_w + min(k0 + c * FEG_THREADS, last);
             if (edge) i = i < 0 ? 0 : (i >= a.n_in ? a.n_in - 1 : i);
-            v[c] = fe_load<SRC>(raw, i, a.src);
+            v[c] = fe_load<SRC>(raw, i);
         }
 #pragma unroll
         for (int c = 0; c < FEG_CHUNK; ++c) {
@@ -269,7 +266,7 @@ __device__ __forceinline__ void feg_stage_interior(const FeArgs& a, const FegArg
     for (int trip = 0; trip < nfull; ++trip, k0 += FEG_THREADS * FEG_CHUNK) {
         float2 v[FEG_CHUNK];
 #pragma unroll
-        for (int c = 0; c < FEG_CHUNK; ++c) v[c] = fe_load<SRC>(raw, i_w + k0 + c * FEG_THREADS, a.src);
+        for (int c = 0; c < FEG_CHUNK; ++c) v[c] = fe_load<SRC>(raw, i_w + k0 + c * FEG_THREADS);
         // the loads first, then everything that does not need them (the phases: most of the work) while they are in flight --
         // left alone the scheduler sinks the loads below the phase arithmetic
         __builtin_amdgcn_sched_barrier(0);
