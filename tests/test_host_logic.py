@@ -357,3 +357,32 @@ def test_zarr_frame_writer_stores_blocks_in_any_order(tmp_path):
     for bad_first, blk in ((5, frames[:3]), (-1, frames[:1]), (0, frames[:1].astype(np.complex128)), (0, frames[:1, :5])):
         with pytest.raises(ValueError):
             w.write(bad_first, blk)
+
+
+def test_cfar_tile_wraparound_indices_advance_like_the_modulo():
+    """cfar_sep_kernel (passiveradar_amd/csrc/cfar.hip) loads its LDS tile with wrap-around row / column indices that are
+    ADVANCED (ii += 4 % H, one conditional subtraction) instead of divided per element; replayed here for maps smaller and
+    larger than the box, tiles on every edge: the advanced index is (start + step k) mod size for every element loaded."""
+    TX, TY = 64, 16
+    for H, W, fw in ((1024, 177, 18), (5, 7, 18), (3, 200, 5), (100, 3, 6), (16, 65, 8), (70, 90, 31), (1, 1, 3), (64, 64, 2)):
+        c = (fw - 1) // 2
+        th, tw = TY + fw - 1, TX + fw - 1
+        for by in range(-(-H // TY)):
+            for bx in range(-(-W // TX)):
+                i0, j0 = by * TY, bx * TX
+                for tq in range(4):
+                    ii = (i0 + c - (fw - 1) + tq) % H            # C's % then "if (ii < 0) ii += H" == Python's %
+                    rstep = 4 % H
+                    for r in range(tq, th, 4):
+                        assert ii == (i0 + c - (fw - 1) + r) % H
+                        ii += rstep
+                        if ii >= H:
+                            ii -= H
+                for tx in (0, 1, 31, 63):
+                    jj = (j0 + c - (fw - 1) + tx) % W
+                    sstep = 64 % W
+                    for s_ in range(tx, tw, 64):
+                        assert jj == (j0 + c - (fw - 1) + s_) % W
+                        jj += sstep
+                        if jj >= W:
+                            jj -= W
