@@ -176,7 +176,7 @@ typedef struct prc_ls_desc {
                               linear correlations, linear FIR); 1: LS_Filter semantics (:6-56:
                               circular data matrix => circular correlations and FIR)        */
     int32_t max_blocks;    /* workspace is sized for this many independent blocks           */
-    int32_t method;        /* 0 auto (= 3 when it fits; = 4 from 250 taps on blocks of >= 65536 samples), 1 time-domain kernels, 2 FFT kernels that
+    int32_t method;        /* 0 auto (= 3 when it fits; = 4 from 120 taps on blocks of >= 65536 samples), 1 time-domain kernels, 2 FFT kernels that
                               recompute the reference spectra per Doppler bin, 3 FFT kernels with
                               the reference spectra cached in HBM between Doppler bins, 4 the chain
                               of method 3 on 4096-point transforms where it applies (linear form,

@@ -919,12 +919,13 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     p->method = d->method;
     if (p->method == 0) p->method = (ls_fft_supported(T) || ls_team_supported(T)) ? 2 : 1;
     if (p->method == 3) p->method = 2;          // same kernels; d->method == 3 only adds the spectrum cache
-    // The cached-spectrum chain on 4096-point transforms (method 4; AUTO from 250 taps on blocks of >= 16 pieces): the
+    // The cached-spectrum chain on 4096-point transforms (method 4; AUTO from 120 taps on blocks of >= 16 pieces): the
     // spectrum cache costs 32768 / (4097 - T) bytes per sample instead of 8192 / (1025 - T).  Measured on the five-bin
-    // chain at 256 chunks of 1.2 M samples (tools/ls_chain_bench.py): T = 64 / 128 / 192 / 256 / 266 / 384 / 512 / 768
-    // -> 1.06 / 1.04 / 1.01 / 0.99 / 0.96 / 0.92 / 0.81 / 0.54 of the 1024-point chain's time.
+    // chain at 64 chunks of 1.2 M samples (tools/ls_chain_bench.py, end of round 4: packed first-bin kernel, aligned
+    // pieces): T = 64 / 128 / 192 / 256 / 266 / 384 / 512 / 768 -> 1.05 / 0.92 / 0.97 / 0.92 / 0.91 / 0.90 / 0.82 / 0.64
+    // of the 1024-point chain's time (round 3, when the switch sat at 250 taps: 1.06 / 1.04 / 1.01 / 0.99 / 0.96 / ...).
     const bool team_chain_ok = !d->circular && ls_fft_supported(T) && d->n >= 2 * 4096;
-    if (d->method == 4 || (d->method == 0 && T >= 250 && d->n >= 16 * 4096)) {
+    if (d->method == 4 || (d->method == 0 && T >= 120 && d->n >= 16 * 4096)) {
         if (p->method == 4) p->method = 2;
         if (team_chain_ok) p->team = p->team_chain = true;
     }
