@@ -88,19 +88,36 @@ def synth_segment(torch, nchunks, C, fs, R, seed, device, t0=0.0):
     return ref, srv.to(torch.complex64)
 
 
-def synth_padded(torch, nchunks, C, fs, R, seed, device, seg_chunks=128, add_to=None):
+def seg_chunks_for(C, strong=False):
+    """chunks per generated segment: 64 for the sharded 600 s stream (cfg4), else <= 128 and <= 2 GB per temporary"""
+    return 64 if strong else max(1, min(128, (1 << 28) // C))
+
+
+def stream_segment(torch, k, nchunks, C, fs, R, seed, device, strong=False):
+    """Segment k of a synthetic stream of ``nchunks`` hop chunks, (ref, srv).  The seed is keyed by the segment's first
+    GLOBAL chunk index, so a stream is the same however it is sharded and a test can regenerate any part of it.  Weak
+    workloads cut the last segment short (its circular delays wrap inside what exists); the sharded stream (strong)
+    always generates whole 64-chunk segments and keeps what lies inside the stream."""
+    seg = seg_chunks_for(C, strong)
+    c0 = k * seg
+    m = seg if strong else min(seg, nchunks - c0)
+    a, s = synth_segment(torch, m, C, fs, R, seed * 1000003 + c0, device, t0=c0 * C / fs)
+    keep = min(m, nchunks - c0)
+    return (a, s) if keep == m else (a[:keep * C], s[:keep * C])
+
+
+def synth_padded(torch, nchunks, C, fs, R, seed, device, add_to=None):
     """[C/2 zeros | nchunks chunks | C/2 zeros] reference and surveillance streams, generated segment by
     segment (a 5632-chunk stream is 54 GB per channel; the generator's temporaries are kept to one
     segment).  add_to: an existing padded surveillance stream to accumulate into (further illuminators)."""
     ref_pad = torch.zeros(nchunks * C + C, dtype=torch.complex64, device=device)
     srv_pad = add_to if add_to is not None else torch.zeros(nchunks * C + C, dtype=torch.complex64, device=device)
-    seg_chunks = max(1, min(seg_chunks, (1 << 28) // C))         # <= 2 GB per temporary
-    for c0 in range(0, nchunks, seg_chunks):
-        m = min(seg_chunks, nchunks - c0)
-        a, s = synth_segment(torch, m, C, fs, R, seed * 1000003 + c0, device, t0=c0 * C / fs)
-        lo = C // 2 + c0 * C
-        ref_pad[lo:lo + m * C] = a
-        srv_pad[lo:lo + m * C] += s
+    seg = seg_chunks_for(C)
+    for k in range(-(-nchunks // seg)):
+        a, s = stream_segment(torch, k, nchunks, C, fs, R, seed, device)
+        lo = C // 2 + k * seg * C
+        ref_pad[lo:lo + a.shape[0]] = a
+        srv_pad[lo:lo + a.shape[0]] += s
         del a, s
     return ref_pad, srv_pad
 
@@ -628,10 +645,11 @@ def main():
         # the global chunk index so the stream is the same whatever the sharding
         ref_pad = torch.zeros(max(nlocal, 1) * C + C, dtype=torch.complex64, device=device)
         srv_pad = torch.zeros_like(ref_pad)
-        seg = 64
-        for g0 in range((shard.chunk_lo // seg) * seg, shard.chunk_hi, seg):
-            a, s = synth_segment(torch, seg, C, fs, R, seed0 * 1000003 + g0, device, t0=g0 * C / fs)
-            lo, hi = max(g0, shard.chunk_lo), min(g0 + seg, shard.chunk_hi)
+        seg = seg_chunks_for(C, True)
+        for k in range(shard.chunk_lo // seg, -(-shard.chunk_hi // seg)):
+            a, s = stream_segment(torch, k, total, C, fs, R, seed0, device, strong=True)
+            g0 = k * seg
+            lo, hi = max(g0, shard.chunk_lo), min(g0 + a.shape[0] // C, shard.chunk_hi)
             dst = C // 2 + (lo - shard.chunk_lo) * C
             ref_pad[dst:dst + (hi - lo) * C] = a[(lo - g0) * C:(hi - g0) * C]
             srv_pad[dst:dst + (hi - lo) * C] = s[(lo - g0) * C:(hi - g0) * C]

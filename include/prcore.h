@@ -269,6 +269,11 @@ int prc_deinterleave(const void* raw, int32_t raw_dtype, int64_t n_complex, void
  * + double block phase, as NumPy promotes it (signal_utils.py:24-27, main.py:133-149) */
 int prc_frequency_shift_block(const void* x, void* y, int64_t n, double fc, double fs,
                               double block_phase, void* stream);
+/* frequency_shift with one phase PER SAMPLE (signal_utils.py:24-27 broadcasts any array): phases = DEVICE double[n]
+ * (phases_f32 = 0: float32 ramp + double phase, complex128 out, NumPy's promotion for float64 / integer arrays) or
+ * DEVICE float[n] (phases_f32 = 1: everything in float32, complex64 out, its promotion for float32 arrays) */
+int prc_frequency_shift_phases(const void* x, void* y, int64_t n, double fc, double fs,
+                               const void* phases, int32_t phases_f32, void* stream);
 
 /* ---- CFAR_2D (SURVEY 8f "next" #3): target_detection.py:683-703 ------------------------------ */
 /* X: float32 [nframes][H][W] (|xambg|, H = Doppler rows, W = range columns); out float32 same shape:

@@ -126,6 +126,31 @@ def helper_cases():
          y_ph=ref_su.frequency_shift(x, 80.0, 262184.87, 0.3)[dec])
 
 
+def helper_uneven_cases():
+    """Round 5: argument forms the reference's expressions accept and its own call sites never use -- xcorr of two
+    signals of different lengths (signal_utils.py:29-32: 'valid' correlation of s1 with the padded s2, whichever is
+    longer) and frequency_shift with one phase per sample (signal_utils.py:24-27 broadcasts the array)."""
+    print("xcorr with unequal lengths / frequency_shift with a phase array")
+    a, s = scene.make_scene(3000, 8000.0, 20, scene.scene_seed(95))
+    cases = [(3000, 2500, 4, 9), (3000, 2990, 6, 7), (2000, 3000, 5, 11), (3000, 1500, 0, 0), (1200, 3000, 30, 0),
+             (3000, 2991, 4, 4), (3000, 2992, 4, 4), (64, 3000, 2, 3), (3000, 64, 2, 3)]
+    out = {}
+    for i, (n1, n2, nlead, nlag) in enumerate(cases):
+        out[f"z{i}"] = ref_su.xcorr(a[:n1], s[:n2], nlead, nlag)
+    save("xcorr_uneven", s1=a, s2=s, cases=np.array(cases), **out)
+    n, fs = 24000, 262184.87
+    x, _ = scene.make_scene(n, fs, 8, scene.scene_seed(96))
+    rng = np.random.default_rng(96)
+    ph64 = rng.uniform(-40.0, 40.0, n)
+    ph32 = ph64.astype(np.float32)
+    phi = rng.integers(-9, 10, n)
+    dec = slice(None, None, 8)
+    save("freqshift_phases", seed=scene.scene_seed(96), n=n, fs=fs, stride=8, ph64=ph64, phi=phi,
+         y64=ref_su.frequency_shift(x, 37500.5, fs, ph64)[dec], y32=ref_su.frequency_shift(x, 37500.5, fs, ph32)[dec],
+         yi=ref_su.frequency_shift(x, -12.25, fs, phi)[dec],
+         y1_32=ref_su.frequency_shift(x, 80.0, fs, np.array([0.3], np.float32))[dec])
+
+
 def ls_cases():
     print("LS filters")
     n, L = 12000, 30
@@ -564,6 +589,7 @@ if __name__ == "__main__":
         artefact_check()
         caf_cases()
         helper_cases()
+        helper_uneven_cases()
         ls_cases()
         nlms_cases()
         nlms_long_cases()

@@ -181,17 +181,25 @@ def direct_xambg(refChannel, srvChannel, rangeBins, freqBins, sampleRate):
 # --------------------------------------------------------------------------
 
 def xcorr(s1, s2, nlead, nlag):
-    """signal_utils.py:29-32: z[i] = sum_n s1[n] conj(s2[n - (i - nlead)]), i = 0..nlag+nlead,
-    terms outside either array dropped.  Accumulated in complex128, returned in the
-    inputs' result type (complex64 for complex64 inputs, as SciPy's direct method does)."""
+    """signal_utils.py:29-32: correlate(s1, pad(s2, (nlag, nlead)), mode='valid').  For equal lengths (every call site
+    of the reference) z[i] = sum_n s1[n] conj(s2[n - (i - nlead)]), i = 0..nlag+nlead, terms outside either array
+    dropped.  For unequal lengths SciPy's 'valid' mode slides the shorter of (s1, padded s2) over the longer: with
+    y = pad(s2), m = len(y), K = |m - len(s1)| it returns K + 1 values,
+        m >= len(s1):  z[i] = sum_l s1[l] conj(y[l + K - i])      (correlate swaps its inputs, conjugates, reverses)
+        m <  len(s1):  z[k] = sum_l s1[l + k] conj(y[l]).
+    Accumulated in complex128, returned in the inputs' result type (complex64 for complex64 inputs, as SciPy's direct
+    method does)."""
     s1 = np.asarray(s1)
     s2 = np.asarray(s2)
     n1, n2 = s1.shape[0], s2.shape[0]
-    out = np.zeros(nlag + nlead + 1, dtype=np.complex128)
     a = s1.astype(np.complex128)
     b = s2.astype(np.complex128)
-    for i in range(out.size):
-        d = i - nlead                    # pair s1[n] with s2[n-d]
+    m = n2 + nlag + nlead
+    K = abs(m - n1)
+    out = np.zeros(K + 1, dtype=np.complex128)
+    for i in range(K + 1):
+        # pair s1[n] with s2[n - d]
+        d = (i + nlag - K) if m >= n1 else (nlag + i)
         n_lo = max(0, d)
         n_hi = min(n1, n2 + d)
         if n_hi > n_lo:
@@ -200,21 +208,26 @@ def xcorr(s1, s2, nlead, nlag):
 
 
 def frequency_shift(x, fc, Fs, phase_offset=0):
-    """signal_utils.py:24-27.  The sample index is held as complex64, so for scalar
-    phase_offset the whole phase ramp is evaluated in float32 (NumPy-2 weak-scalar
-    promotion); this restatement spells the float32 steps out:
-        ph[n] = fl32( fl32( fl32(2*pi*fc) * n ) * fl32(1/fl32(Fs)) ) + fl32(phase_offset)
-    (complex64 / real goes through NumPy's Smith division = multiply by the float32
-    reciprocal)."""
+    """signal_utils.py:24-27.  The sample index is held as complex64, so the phase ramp is evaluated in float32
+    (NumPy-2 weak-scalar promotion); this restatement spells the float32 steps out:
+        ph[n] = fl32( fl32( fl32(2*pi*fc) * n ) * fl32(1/fl32(Fs)) )
+    (complex64 / real goes through NumPy's Smith division = multiply by the float32 reciprocal).  What is added to it
+    decides the rest: a scalar phase_offset (or a float32 / float16 array) keeps everything in float32 -- float32 sum,
+    complex64 exponential and product; a float64 or integer ARRAY (main.py:137,146 pass one phase per dask block, the
+    expression takes one per sample just as well) promotes the sum to double: float32 ramp + double phase, complex128
+    exponential and product."""
     x = np.asarray(x)
-    if np.ndim(phase_offset) != 0:
-        # array phase promotes to complex128 (main.py:137,146) -- front-end only
-        nn = np.arange(x.shape[0], dtype=np.complex64)
-        return x * np.exp(1j * 2 * np.pi * fc * nn / Fs + 1j * phase_offset)
     n = np.arange(x.shape[0], dtype=np.float32)
     a = np.float32(2 * np.pi * fc)
     rcp = np.float32(1.0) / np.float32(Fs)
     ph = (a * n) * rcp
+    if np.ndim(phase_offset) != 0:
+        p = np.asarray(phase_offset)
+        if p.dtype in (np.float32, np.float16):
+            ph = ph + p.astype(np.float32)
+            return x * (np.cos(ph) + 1j * np.sin(ph)).astype(np.complex64)
+        ph = ph.astype(np.float64) + p.astype(np.float64)
+        return x * (np.cos(ph) + 1j * np.sin(ph))
     if phase_offset != 0:
         ph = ph + np.float32(phase_offset)
     rot = (np.cos(ph) + 1j * np.sin(ph)).astype(np.complex64)

@@ -107,6 +107,8 @@ _SIGNATURES = {
     "prc_deinterleave": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "prc_frequency_shift_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                             C.c_double, C.c_void_p]),
+    "prc_frequency_shift_phases": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                             C.c_void_p, C.c_int32, C.c_void_p]),
     "prc_cfar2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                              C.c_void_p, C.c_int32, C.c_void_p]),
     "prc_decimate_iir": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(IirDesc), C.c_void_p, C.c_void_p]),

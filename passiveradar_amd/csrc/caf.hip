@@ -109,6 +109,11 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
                 "divides by q = int(n/freq_bins) = 0", d->freq_bins, (long long)d->n);
     PRC_REQUIRE(d->range_bins < d->n, PRC_EINVAL, "prc_caf_plan_create: range_bins >= n");
     PRC_REQUIRE(d->ntaps == 0 || d->taps_host, PRC_EINVAL, "prc_caf_plan_create: ntaps without taps");
+    // every argument check comes before the plan exists (a failed check after `new` leaked it); `reserved`
+    // must be 0, which also catches a host compiled against the shorter descriptor of header version 310
+    PRC_REQUIRE(d->multi >= PRC_CAF_MULTI_AUTO && d->multi <= PRC_CAF_MULTI_PAIRS, PRC_EINVAL,
+                "prc_caf_plan_create: unknown multi mode %d", d->multi);
+    PRC_REQUIRE(d->reserved == 0, PRC_EINVAL, "prc_caf_plan_create: prc_caf_desc.reserved must be 0 (got %d)", d->reserved);
     prc_caf_plan* p = new prc_caf_plan();
     p->desc = *d;
     p->desc.taps_host = nullptr;
@@ -149,8 +154,6 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
         delete p;
         return PRC_EUNSUPPORTED;
     }
-    PRC_REQUIRE(d->multi >= PRC_CAF_MULTI_AUTO && d->multi <= PRC_CAF_MULTI_PAIRS, PRC_EINVAL,
-                "prc_caf_plan_create: unknown multi mode %d", d->multi);
     p->multi = d->multi != PRC_CAF_MULTI_AUTO ? d->multi : (int)prc_opt(PRC_OPT_CAF_MULTI_MODE);
     if (p->multi == PRC_CAF_MULTI_AUTO) {
         // measured on MI355X, four illuminators (tools/caf_bench.py --nref 4): config-3 span (1025

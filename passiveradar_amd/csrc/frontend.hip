@@ -606,3 +606,46 @@ extern "C" int prc_frequency_shift_block(const void* x, void* y, int64_t n, doub
     PRC_LAUNCH_CHECK();
     return PRC_OK;
 }
+
+// frequency_shift with ONE PHASE PER SAMPLE (signal_utils.py:24-27 broadcasts an array phase_offset of the signal's
+// length as readily as main.py's one value per block).  NumPy's promotion decides the arithmetic: a float64 (or integer)
+// array makes the sum double -- float32 ramp + double phase, exponential and product in double, complex128 out; a
+// float32 array keeps the sum, the exponential and the product in float32, complex64 out.
+template <bool F32>
+__global__ void freq_shift_phases_kernel(const float2* __restrict__ x, void* __restrict__ y, int64_t n,
+                                         PhaseRamp pr, const void* __restrict__ phase) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float ph32 = (pr.a32 * (float)i) * pr.rcp32;
+        const float2 v = x[i];
+        if (F32) {
+            float s, c;
+            sincosf(ph32 + ((const float*)phase)[i], &s, &c);
+            ((float2*)y)[i] = cmul(v, make_float2(c, s));
+        } else {
+            double s, c;
+            sincos((double)ph32 + ((const double*)phase)[i], &s, &c);
+            ((double2*)y)[i] = make_double2((double)v.x * c - (double)v.y * s, (double)v.x * s + (double)v.y * c);
+        }
+    }
+}
+
+extern "C" int prc_frequency_shift_phases(const void* x, void* y, int64_t n, double fc, double fs,
+                                          const void* phases, int32_t phases_f32, void* stream) {
+    PRC_REQUIRE(x && y && phases && n > 0 && fs != 0.0, PRC_EINVAL, "prc_frequency_shift_phases: bad argument");
+    PhaseRamp pr;
+    pr.a32 = (float)(2.0 * 3.14159265358979323846 * fc);
+    pr.rcp32 = 1.0f / (float)fs;
+    pr.off32 = 0.f;
+    pr.enabled = 1;
+    int64_t blocks = ceil_div64(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    if (phases_f32)
+        hipLaunchKernelGGL(freq_shift_phases_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float2*)x, y, n, pr, phases);
+    else
+        hipLaunchKernelGGL(freq_shift_phases_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const float2*)x, y, n, pr, phases);
+    PRC_LAUNCH_CHECK();
+    return PRC_OK;
+}

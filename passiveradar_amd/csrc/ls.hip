@@ -903,7 +903,9 @@ static bool levinson_c_global(int T) { return sizeof(double2) * ((size_t)3 * T) 
 static size_t levinson_lds(int T) { return sizeof(double2) * ((size_t)(levinson_c_global(T) ? 2 : 3) * T); }
 static size_t fir_lds(int T) { return sizeof(float2) * ((size_t)T + FIR_SPAN + T - 1); }
 
-extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
+// allow_cache = false: the retry after a mandatory allocation failed while the (optional) spectrum cache was held --
+// the same plan without the cache, i.e. on the kernels that recompute the spectra
+static int ls_plan_create_impl(prc_ls_plan** plan, const prc_ls_desc* d, bool allow_cache) {
     PRC_REQUIRE(plan && d, PRC_EINVAL, "prc_ls_plan_create: null argument");
     PRC_REQUIRE(d->n > 0 && d->filter_len > 0 && d->peek >= 0 && d->max_blocks > 0, PRC_EINVAL,
                 "prc_ls_plan_create: non-positive size");
@@ -945,6 +947,7 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
     const int64_t limit_mb = prc_opt(PRC_OPT_LS_CACHE_LIMIT_MB);
     auto try_cache = [&](int64_t per_block) {
         const size_t bytes = sizeof(float2) * (size_t)d->max_blocks * (size_t)per_block;
+        if (!allow_cache) return false;
         if (limit_mb > 0 && bytes > (size_t)limit_mb * 1048576u) return false;
         if (hipMalloc(&p->d_cache, bytes) != hipSuccess) {
             p->d_cache = nullptr;
@@ -1013,12 +1016,20 @@ extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
         e = hipFuncSetAttribute((const void*)fir_subtract_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
+        const bool held_cache = allow_cache && p->d_cache != nullptr;
         prc_set_error("prc_ls_plan_create: device setup failed: %s", hipGetErrorString(e));
         prc_ls_plan_destroy(p);
+        (void)hipGetLastError();
+        // near the HBM limit the optional cache may have taken what a mandatory buffer needed: once more without it
+        if (held_cache && e == hipErrorOutOfMemory) return ls_plan_create_impl(plan, d, false);
         return PRC_EHIP;
     }
     *plan = p;
     return PRC_OK;
+}
+
+extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
+    return ls_plan_create_impl(plan, d, true);
 }
 
 static PhaseRamp make_ramp(double fc, double fs, double phase_offset) {

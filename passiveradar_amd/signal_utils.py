@@ -10,40 +10,81 @@ __all__ = ["xcorr", "frequency_shift", "deinterleave_IQ", "resample", "front_end
            "decimate_iir"]
 
 
+def _xcorr_equal_lengths(s1, s2, nlead, nlag):
+    """xcorr of two signals of different lengths as the equal-length sum on zero-extended copies (host logic, no device
+    call): returns (e1, e2, nlead', nlag') with xcorr(s1, s2, nlead, nlag) == xcorr(e1, e2, nlead', nlag')"""
+    n1, n2 = s1.shape[0], s2.shape[0]
+    m = n2 + nlag + nlead
+    K = abs(m - n1)
+    if m >= n1:
+        # offsets K - nlag - i of s2 against s1: lead' = K - nlag (when negative, s2 is delayed by that much first)
+        lead = K - nlag
+        front = max(-lead, 0)
+        e2 = np.zeros(max(n1, n2 + front), np.complex64)
+        e2[front:front + n2] = s2
+        e1 = np.zeros(e2.shape[0], np.complex64)
+        e1[:n1] = s1
+        return e1, e2, lead + front, K - (lead + front)
+    e2 = np.zeros(n1, np.complex64)                         # the padded s2, zero-extended to len(s1)
+    e2[nlag:nlag + n2] = s2
+    return s1, e2, 0, K
+
+
 def xcorr(s1, s2, nlead, nlag):
-    """signal_utils.py:29-32: z[i] = sum_n s1[n] conj(s2[n-(i-nlead)]), i = 0..nlag+nlead (complex64)."""
+    """signal_utils.py:29-32: ``correlate(s1, pad(s2, (nlag, nlead)), mode='valid')``, complex64.
+
+    Equal lengths (every call site of the reference): z[i] = sum_n s1[n] conj(s2[n-(i-nlead)]), i = 0..nlag+nlead.
+    The reference's expression accepts ANY two lengths; with m = len(s2) + nlag + nlead and K = |m - len(s1)| SciPy's
+    'valid' mode returns K + 1 values:
+      m >= len(s1):  z[i] = sum_l s1[l]   conj(s2[l + K - i - nlag]),  i = 0..K   (the padded s2 slides over s1)
+      m <  len(s1):  z[k] = sum_l s1[l+k] conj(s2[l - nlag]),          k = 0..K   (s1 slides over the padded s2)
+    Both are the equal-length sum on zero-extended copies (zeros add nothing), which is how they reach prc_xcorr."""
     s1 = np.ascontiguousarray(s1, dtype=np.complex64)
     s2 = np.ascontiguousarray(s2, dtype=np.complex64)
-    if s1.shape != s2.shape:
-        raise ValueError("Input vectors must have the same length")
-    n = s1.shape[0]
+    if s1.ndim != 1 or s2.ndim != 1:
+        raise ValueError("xcorr takes one-dimensional signals")
+    nlead, nlag = int(nlead), int(nlag)
+    if nlead < 0 or nlag < 0:
+        raise ValueError("index can't contain negative values")          # np.pad's complaint about (nlag, nlead)
+    if s1.shape[0] != s2.shape[0]:
+        s1, s2, nlead, nlag = _xcorr_equal_lengths(s1, s2, nlead, nlag)
+    n1 = s1.shape[0]
+    n = n1
     st = engine.staging()
     d1 = st.get("xc_1", 8 * n)
     d2 = st.get("xc_2", 8 * n)
     do = st.get("xc_o", 8 * (nlag + nlead + 1))
     d1.upload(s1)
     d2.upload(s2)
-    check(lib().prc_xcorr(d1.ptr, d2.ptr, n, int(nlead), int(nlag), do.ptr, None))
+    check(lib().prc_xcorr(d1.ptr, d2.ptr, n, nlead, nlag, do.ptr, None))
     return do.download((nlag + nlead + 1,), np.complex64)
 
 
 def frequency_shift(x, fc, Fs, phase_offset=0):
-    """signal_utils.py:24-27 with the reference's float32 phase ramp; scalar phase_offset only
-    (the array form is the front end's block-phase trick, main.py:125-149, outside this path)."""
+    """signal_utils.py:24-27 with the reference's float32 phase ramp.  phase_offset: a scalar (complex64 result), or an
+    array NumPy broadcasts against x -- one value (main.py:133-149: the starting phase of a dask block) or one per
+    sample; a float64 / integer array promotes the result to complex128 (float32 ramp + double phase, exponential in
+    double), a float32 array keeps it complex64, as in the reference."""
     if np.ndim(phase_offset) != 0:
-        # array phase offset (main.py:133-149: one starting phase per dask block): NumPy promotes the
-        # result to complex128 -- float32 ramp + double phase, exponential in double
-        if np.size(phase_offset) != 1:
-            raise ValueError("operands could not be broadcast together: phase_offset must hold one value per block")
+        ph = np.asarray(phase_offset)
         x = np.ascontiguousarray(x, dtype=np.complex64)
         n = x.shape[0]
+        if ph.ndim != 1 or ph.shape[0] not in (1, n) or x.ndim != 1:
+            raise ValueError(f"operands could not be broadcast together with shapes ({n},) {ph.shape}")
+        f32 = ph.dtype in (np.float32, np.float16)
         st = engine.staging()
         dx = st.get("fs_x", 8 * n)
-        dy = st.get("fs_y128", 16 * n)
         dx.upload(x)
-        check(lib().prc_frequency_shift_block(dx.ptr, dy.ptr, n, float(fc), float(Fs),
-                                              float(np.asarray(phase_offset).reshape(-1)[0]), None))
-        return dy.download((n,), np.complex128)
+        if ph.shape[0] == 1 and not f32:
+            dy = st.get("fs_y128", 16 * n)
+            check(lib().prc_frequency_shift_block(dx.ptr, dy.ptr, n, float(fc), float(Fs), float(ph[0]), None))
+            return dy.download((n,), np.complex128)
+        ph = np.ascontiguousarray(np.broadcast_to(ph, (n,)), dtype=np.float32 if f32 else np.float64)
+        dp = st.get("fs_ph", ph.nbytes)
+        dp.upload(ph)
+        dy = st.get("fs_y128", (8 if f32 else 16) * n)
+        check(lib().prc_frequency_shift_phases(dx.ptr, dy.ptr, n, float(fc), float(Fs), dp.ptr, int(f32), None))
+        return dy.download((n,), np.complex64 if f32 else np.complex128)
     x = np.ascontiguousarray(x, dtype=np.complex64)
     n = x.shape[0]
     st = engine.staging()

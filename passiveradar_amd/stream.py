@@ -183,6 +183,8 @@ def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, com
     import torch
     if shard.world == 1 and comm is None:
         if out is not None and out.data_ptr() != local.data_ptr():
+            if tuple(out.shape) != tuple(local.shape):
+                raise ValueError(f"gather_frames: out has shape {tuple(out.shape)}, the frames {tuple(local.shape)}")
             out.copy_(local)
             local = out
         return (local, _NoWork()) if async_op else local
@@ -191,10 +193,6 @@ def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, com
     if len(counts) != shard.world:
         raise ValueError(f"gather_frames: {len(counts)} counts for a world of {shard.world}")
     total = sum(counts)
-    if total == 0:
-        # a round in which no rank has frames (more rounds than frames): nothing to move, no collective, no buffers
-        empty = torch.empty((0, F, cols), dtype=torch.complex64, device=local.device)
-        return (empty, _NoWork()) if async_op else empty
     if comm is not None:
         # the C-ABI path knows nothing of torch.distributed: ranks, the root and the world are the communicator's own
         # (a FrameComm built over a sub-group, or over any other side channel, numbers its ranks from 0)
@@ -206,6 +204,13 @@ def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, com
         me = dist.get_rank(group) if group is not None else dist.get_rank()
         on_dst_global = dist.get_rank() == dst           # dst is a GLOBAL rank on the torch path, also for sub-groups
     on_dst = (me == dst) if comm is not None else on_dst_global
+    if total == 0:
+        # a round in which no rank has frames (more rounds than frames): nothing to move, no collective, no buffers; the
+        # documented contract holds all the same -- the (empty) result on dst, None elsewhere
+        empty = None
+        if on_dst:
+            empty = out[:0] if out is not None else torch.empty((0, F, cols), dtype=torch.complex64, device=local.device)
+        return (empty, _NoWork()) if async_op else empty
     if int(local.shape[0]) != counts[me]:
         raise ValueError(f"gather_frames: rank {me} holds {int(local.shape[0])} frames, counts say {counts[me]}")
     res = None
@@ -453,6 +458,16 @@ class HipBackend:
         phases = 2 * np.pi * (np.arange(nblocks) + int(block0)) * per_block * (offset_freq / input_sample_rate)
         if out is None:
             out = torch.empty(nblocks * plan.n_out, dtype=torch.complex64, device=self.device)
+        else:
+            # the kernel writes nblocks * n_out complex64 straight into the caller's tensor: anything else than a
+            # contiguous complex64 tensor of at least that size on this device would be a silent out-of-bounds write
+            if not (torch.is_tensor(out) and out.is_cuda and out.device == self.device):
+                raise ValueError(f"front_end: out must be a tensor on {self.device}")
+            if out.dtype != torch.complex64 or out.dim() != 1 or not out.is_contiguous():
+                raise ValueError("front_end: out must be a contiguous one-dimensional complex64 tensor")
+            if out.numel() < nblocks * plan.n_out:
+                raise ValueError(f"front_end: out holds {out.numel()} samples, {nblocks} blocks of {plan.n_out} need "
+                                 f"{nblocks * plan.n_out}")
         with torch.cuda.device(self.device):
             for b0 in range(0, nblocks, max_blocks):
                 nb = min(max_blocks, nblocks - b0)

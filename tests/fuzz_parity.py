@@ -34,13 +34,25 @@ def note(kind, err, tol, desc):
 def worker(wseed):
   rng = np.random.default_rng(wseed)
   while time.time() - t0 < budget:
-      k = rng.integers(0, 22) if KINDS is None else int(rng.choice(KINDS))
+      k = rng.integers(0, 24) if KINDS is None else int(rng.choice(KINDS))
       if k == 20:     # power-of-two Doppler bin counts: the column-FFT Doppler kernel (256 .. 4096), ragged column tiles
           F = int(rng.choice([256, 512, 1024, 2048, 4096])); q = int(rng.integers(4, 40)); N = F * q + int(rng.integers(0, F))
           R = int(rng.integers(1, min(700, N // 2 - 1)))
           ref, srv = scene.make_scene(N, 1e5, min(R, 200), int(rng.integers(1 << 30)))
           w = None if rng.random() < 0.5 else np.kaiser(N, 5.0)
           note("caf_column_doppler", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("cafcol", N, R, F, w is not None))
+      elif k == 22:   # xcorr of two signals of different lengths (signal_utils.py:29-32 accepts any two)
+          n1, n2 = int(rng.integers(1, 30000)), int(rng.integers(1, 30000)); nlead = int(rng.integers(0, 60)); nlag = int(rng.integers(0, 300))
+          a = scene.white_reference(n1, int(rng.integers(1 << 30))); b = scene.white_reference(n2, int(rng.integers(1 << 30)))
+          g, e = xcorr(a, b, nlead, nlag), O.xcorr(a, b, nlead, nlag)
+          scale = float(np.sqrt(min(n1, n2))) * 4                        # a lag's sum of min(n1, n2) unit-variance products
+          note("xcorr_uneven", float(np.abs(g - e).max()) / scale if g.shape == e.shape else 1.0, 2e-5, ("xcu", n1, n2, nlead, nlag))
+      elif k == 23:   # frequency_shift with one phase per sample: float64 / integer (complex128 out) or float32 (complex64 out)
+          n = int(rng.integers(10, 50000)); fc = float(rng.uniform(-3e5, 3e5))
+          x = scene.white_reference(n, int(rng.integers(1 << 30)))
+          ph = rng.uniform(-50, 50, n).astype(rng.choice([np.float64, np.float32, np.int64]))
+          g, e = frequency_shift(x, fc, 2.4e6, ph), O.frequency_shift(x, fc, 2.4e6, ph)
+          note("freqshift_phases", rel(g, e) if g.dtype == e.dtype else 1.0, 2e-6, ("fsp", n, fc, str(ph.dtype)))
       elif k == 21:   # several illuminators against one surveillance channel, every mode of prc_caf_execute_multi
           nref = int(rng.integers(1, 6)); F = int(rng.choice([2, 8, 16, 256])); N = int(rng.integers(max(8192, 4 * F), 200000))
           R = int(rng.integers(2, min(4000, N // 2 - 1)))

@@ -1,0 +1,66 @@
+"""The BENCHMARKED configurations at their real sizes: bench.py's default 5632-frame step
+(6.8e9 samples per stream, byte offsets beyond 2^35), the 1199-frame 600 s stream and config 3's 3072-hop NLMS launch
+are held, frame for frame, against an independent pass over the regenerated stream and one frame end to end against
+the CPU oracle.  Semantics: main.py:169-194 (LS_Filter_Multiple / NLMS_filter per hop chunk, fast_xambg per
+50 %-overlapped CPI)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gpu_ready")]
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check(tmp_path, wl, bench_args, nframes, strong, oracle_lags=None, window_segs=2, batch=64):
+    import torch
+    sys.path.insert(0, REPO)
+    import bench
+    import bench_check
+    torch.cuda.empty_cache()                      # the benchmark keeps 160-190 GB resident: give back what earlier tests cached
+    line, d = bench_check.run_bench(bench_args, str(tmp_path / f"{wl}.npz"))
+    assert line["config"]["frames_per_step_total"] == nframes and int(d["nframes"]) == nframes
+    pick = [int(f) for f in d["frame_index"]]
+    assert pick == sorted({0, 1, nframes // 2, nframes - 1})
+    last = nframes - 1
+    sums, maps_at, chunks_at = bench_check.independent_pass(bench, torch, wl, nframes, int(d["seed0"]), strong, pick,
+                                                            oracle_frame=last, window_segs=window_segs, batch=batch)
+    torch.cuda.empty_cache()
+    got = d["ill0_frames"]
+    errs = {f: rel_err(got[j], maps_at[f]) for j, f in enumerate(pick)}
+    # not bit-equal by construction: a plan of 258 blocks and a plan of 66 cut a chunk into different runs of pieces per
+    # team, so the float32 partial sums of the correlations group differently (1e-6 measured at 600 frames)
+    assert max(errs.values()) < 5e-6, errs
+    # every frame's sum: each of the maps came from the right chunks (the cells' 1e-6 differences add incoherently
+    # while the sum itself mostly cancels -- 1.2e-5 of the largest sum measured at 600 frames)
+    e_sum = rel_err(d["ill0_sums"], sums)
+    assert e_sum < 1e-4, e_sum
+    # the LAST frame (the highest byte offsets of the resident streams) end to end on the CPU
+    exp = bench_check.oracle_frame_map(bench, wl, nframes, last, chunks_at, lags=oracle_lags)
+    mine = got[pick.index(last)]
+    if oracle_lags is not None:
+        mine = mine[:, -(oracle_lags + 1):]
+    e_or = float(np.abs(mine - exp).max() / np.abs(got[pick.index(last)]).max())
+    print(f"{wl}: {nframes} frames, picked maps vs independent pass {errs}, sums {e_sum:.2e}, last frame vs oracle {e_or:.2e}; "
+          f"{line['value']:.0f} frames/s in the dumped run")
+    assert e_or < 1e-4, e_or
+
+
+def test_default_bench_step_at_its_real_size(tmp_path):
+    """bench.py with no arguments but --dump: 5632 frames per step, 22 sub-batches of 256 over three LS plans"""
+    _check(tmp_path, "cfg2", [], 5632, False)
+
+
+def test_600_s_stream_at_its_real_size(tmp_path):
+    """bench.py --workload cfg4: all 1199 frames of the 600 s stream (the test of rounds 3-4 ran 21)"""
+    _check(tmp_path, "cfg4", ["--workload", "cfg4"], 1199, True)
+
+
+def test_config3_nlms_launch_at_its_real_size(tmp_path):
+    """bench.py --workload cfg3: 3072 hop chunks of 2.5 M samples through ONE NLMS launch (three wavefronts per SIMD),
+    then 3072 frames of 1024 x 1025; the oracle leg runs the C twin's NLMS over the two hops under the last frame and
+    the CAF on delays 0..127 (the full 1025-lag CAF takes two minutes on one host core)"""
+    _check(tmp_path, "cfg3", ["--workload", "cfg3"], 3072, False, oracle_lags=127, window_segs=5, batch=32)

@@ -129,6 +129,32 @@ def test_xcorr_and_freqshift():
         assert np.abs(y[::st] - gf[key]).max() < 2e-6
 
 
+def test_xcorr_of_unequal_lengths_and_phase_arrays():
+    """argument forms the reference's expressions accept -- xcorr of two signals of different lengths
+    (signal_utils.py:29-32) and frequency_shift with one phase per sample (signal_utils.py:24-27), against goldens made
+    by the reference; the error conventions of NumPy for what cannot broadcast"""
+    from passiveradar_amd.signal_utils import frequency_shift, xcorr
+    g = load_golden("xcorr_uneven")
+    scale = np.abs(g["z0"]).max()
+    for i, (n1, n2, nlead, nlag) in enumerate(g["cases"]):
+        z = xcorr(g["s1"][:n1], g["s2"][:n2], int(nlead), int(nlag))
+        want = g[f"z{i}"]
+        assert z.shape == want.shape and z.dtype == np.complex64
+        assert np.abs(z - want).max() < 2e-6 * scale, i
+    gf = load_golden("freqshift_phases")
+    n, fs, st = int(gf["n"]), float(gf["fs"]), int(gf["stride"])
+    x, _ = scene.make_scene(n, fs, 8, int(gf["seed"]))
+    for key, fc, ph in (("y64", 37500.5, gf["ph64"]), ("y32", 37500.5, gf["ph64"].astype(np.float32)), ("yi", -12.25, gf["phi"]),
+                        ("y1_32", 80.0, np.array([0.3], np.float32))):
+        y = frequency_shift(x, fc, fs, ph)
+        assert y.dtype == gf[key].dtype, key
+        assert np.abs(y[::st] - gf[key]).max() < 2e-6, key
+    with pytest.raises(ValueError):
+        frequency_shift(x, 1.0, fs, np.zeros(7))
+    with pytest.raises(ValueError):
+        xcorr(x[:100], x[:90], -1, 3)
+
+
 @pytest.mark.parametrize("name", ["ls_toeplitz_white", "ls_toeplitz_peek0", "ls_toeplitz_coloured"])
 def test_ls_toeplitz_golden(name, ls_method):
     from passiveradar_amd.clutter_removal import LS_Filter_Toeplitz

@@ -386,3 +386,24 @@ def test_cfar_tile_wraparound_indices_advance_like_the_modulo():
                         jj += sstep
                         if jj >= W:
                             jj -= W
+
+
+def test_xcorr_of_unequal_lengths_reduces_to_the_equal_length_sum():
+    """signal_utils.py:29-32 with len(s1) != len(s2): the drop-in zero-extends both signals so that the equal-length
+    entry point (prc_xcorr) computes the reference's 'valid' correlation -- the mapping itself is host logic and is held
+    here against the oracle's restatement of SciPy's rule (the oracle against the reference: tests/golden/xcorr_uneven)"""
+    from oracle import np_oracle as O
+    from passiveradar_amd.signal_utils import _xcorr_equal_lengths
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        n1, n2 = (int(v) for v in rng.integers(1, 150, 2))
+        nlead, nlag = (int(v) for v in rng.integers(0, 40, 2))
+        if n1 == n2:
+            continue
+        s1 = (rng.standard_normal(n1) + 1j * rng.standard_normal(n1)).astype(np.complex64)
+        s2 = (rng.standard_normal(n2) + 1j * rng.standard_normal(n2)).astype(np.complex64)
+        e1, e2, lead, lag = _xcorr_equal_lengths(s1, s2, nlead, nlag)
+        assert e1.shape == e2.shape and lead >= 0 and lag >= 0
+        want = O.xcorr(s1, s2, nlead, nlag)
+        assert want.shape == (abs(n2 + nlag + nlead - n1) + 1,)
+        assert np.array_equal(O.xcorr(e1, e2, lead, lag), want)

@@ -59,6 +59,30 @@ def test_xcorr():
     assert rel_err(O.xcorr(g["s1"], g["s1"], 0, 15), g["z_auto"]) < 2e-6
 
 
+def test_xcorr_of_unequal_lengths():
+    """signal_utils.py:29-32 takes any two lengths ('valid' correlation of s1 with the padded s2, whichever is longer):
+    |n1 - (n2 + nlag + nlead)| + 1 values, reference-made golden"""
+    g = load_golden("xcorr_uneven")
+    for i, (n1, n2, nlead, nlag) in enumerate(g["cases"]):
+        z = O.xcorr(g["s1"][:n1], g["s2"][:n2], int(nlead), int(nlag))
+        want = g[f"z{i}"]
+        assert z.shape == want.shape == (abs(n2 + nlag + nlead - n1) + 1,) and z.dtype == np.complex64
+        assert np.abs(z - want).max() < 2e-6 * np.abs(g[f"z{0}"]).max(), i
+
+
+def test_frequency_shift_with_a_phase_per_sample():
+    """signal_utils.py:24-27 with an array phase_offset of the signal's length: complex128 for float64 / integer
+    phases, complex64 for float32 ones (NumPy's promotion), reference-made golden"""
+    g = load_golden("freqshift_phases")
+    n, fs, st = int(g["n"]), float(g["fs"]), int(g["stride"])
+    x, _ = scene.make_scene(n, fs, 8, int(g["seed"]))
+    for key, fc, ph, dt in (("y64", 37500.5, g["ph64"], np.complex128), ("y32", 37500.5, g["ph64"].astype(np.float32), np.complex64),
+                            ("yi", -12.25, g["phi"], np.complex128), ("y1_32", 80.0, np.array([0.3], np.float32), np.complex64)):
+        y = O.frequency_shift(x, fc, fs, ph)
+        assert y.dtype == dt and y.dtype == g[key].dtype, key
+        assert np.abs(y[::st] - g[key]).max() < 2e-6, key
+
+
 def test_frequency_shift():
     g = load_golden("freqshift")
     x, _ = scene.make_scene(int(g["n"]), float(g["fs"]), 8, int(g["seed"]))
