@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PRC_VERSION 401   /* 401: prc_comm_loopback, PRC_OPT_FE_METHOD, PRC_OPT_CFAR_METHOD; 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
+#define PRC_VERSION 500   /* 500: prc_frequency_shift_phases, prc_frontend_execute2, prc_cfar2d_c64, prc_mem_info, PRC_OPT_MARKERS; 401: prc_comm_loopback, PRC_OPT_FE_METHOD, PRC_OPT_CFAR_METHOD; 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
                              prc_comm_count; 310: prc_ls_desc.method = 4, NLMS up to 8192 taps */
 
 typedef enum prc_status {
@@ -50,6 +50,7 @@ int prc_set_device(int device);
 int prc_get_device(int* device);       /* the calling thread's current HIP device */
 /* Device-memory helpers for hosts that do not bring their own allocator (the NumPy-facing
  * drop-in functions use these; torch-based callers pass tensor.data_ptr() instead). */
+int prc_mem_info(size_t* free_bytes, size_t* total_bytes);   /* hipMemGetInfo of the current device */
 int prc_malloc(void** dptr, size_t bytes);
 int prc_free(void* dptr);
 int prc_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
@@ -85,7 +86,11 @@ typedef enum prc_option {
                                      thread; 1 = one output per thread; 2 = the group form or PRC_EUNSUPPORTED                */
     PRC_OPT_CFAR_METHOD = 10,     /* prc_cfar2d, read per call: 0 (default) = separable sums (rows, then columns) where the tile fits
                                      LDS, 1 = every tap of the box per output                                               */
-    PRC_OPT_COUNT_ = 11
+    PRC_OPT_MARKERS = 11,         /* 1: every prc_*_execute (and the other device entry points) opens a roctx range named after
+                                     itself -- rocprofv3 --marker-trace shows the library's calls around its kernels.  The roctx
+                                     library (librocprofiler-sdk-roctx.so.1, else libroctx64.so.4) is bound at run time, the first
+                                     time the option is set; PRC_EUNSUPPORTED if neither loads.  Default 0: nothing is loaded    */
+    PRC_OPT_COUNT_ = 12
 } prc_option;
 int prc_set_option(int32_t option, int64_t value);     /* PRC_EINVAL for an unknown option or a value out of range */
 int prc_get_option(int32_t option, int64_t* value);
@@ -281,6 +286,10 @@ int prc_frequency_shift_phases(const void* x, void* y, int64_t n, double fc, dou
  * with the (gw+1)^2 guard hole and the 1/(fw^2-gw^2) gain of the reference, normalised by mean|X|. */
 int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int32_t gw, int32_t use_thresh,
                float thresh, float* out, int32_t nframes, void* stream);
+/* CFAR_2D(np.abs(X), fw, gw[, thresh]) as range_doppler_plot.py:56-57 calls it: X = the complex64 range-Doppler maps
+ * [nframes][H][W] themselves, |X| (hypotf, as np.abs) taken while the tiles are loaded -- one read of the complex map */
+int prc_cfar2d_c64(const void* X, int32_t H, int32_t W, int32_t fw, int32_t gw, int32_t use_thresh,
+                   float thresh, float* out, int32_t nframes, void* stream);
 
 /* ---- channel offset estimation (SURVEY 8f "next" #2): signal_utils.py:73-78 ------------------- */
 /* The zero-phase IIR decimator of scipy.signal.decimate(x, q) (ftype 'iir', zero_phase=True:

@@ -23,7 +23,7 @@ CAF_MULTI_MODES = {"auto": CAF_MULTI_AUTO, "turns": CAF_MULTI_TURNS, "shared": C
 # prc_option
 (OPT_CAF_MULTI_MODE, OPT_CAF_GROUP_MB, OPT_LS_TEAM_PIECES, OPT_LS_TEAM_ALIGN, OPT_NLMS_WAVES, OPT_LS_CACHE_LIMIT_MB,
  OPT_NLMS_WG_WAVES, OPT_CAF_XCD_CONTIG, OPT_CAF_PAIR_FRAMES, OPT_FE_METHOD,
- OPT_CFAR_METHOD) = range(11)
+ OPT_CFAR_METHOD, OPT_MARKERS) = range(12)
 CAF_MAX_REFS = 8
 COMM_ID_BYTES = 128
 
@@ -69,6 +69,7 @@ _SIGNATURES = {
     "prc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "prc_set_device": (C.c_int, [C.c_int]),
     "prc_get_device": (C.c_int, [C.POINTER(C.c_int)]),
+    "prc_mem_info": (C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "prc_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "prc_free": (C.c_int, [C.c_void_p]),
     "prc_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -111,6 +112,8 @@ _SIGNATURES = {
                                              C.c_void_p, C.c_int32, C.c_void_p]),
     "prc_cfar2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                              C.c_void_p, C.c_int32, C.c_void_p]),
+    "prc_cfar2d_c64": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                 C.c_void_p, C.c_int32, C.c_void_p]),
     "prc_decimate_iir": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(IirDesc), C.c_void_p, C.c_void_p]),
     "prc_channel_offset": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(IirDesc), C.c_int64,
                                      C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
@@ -214,6 +217,13 @@ def get_option(option):
     v = C.c_int64(0)
     check(lib().prc_get_option(int(option), C.byref(v)))
     return int(v.value)
+
+
+def mem_info():
+    """(free, total) bytes of the current device's memory (hipMemGetInfo)"""
+    f, t = C.c_size_t(0), C.c_size_t(0)
+    check(lib().prc_mem_info(C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
 
 
 def rccl_version():

@@ -323,6 +323,7 @@ static int run_doppler(prc_caf_plan* p, void* out, int s0, int ns, hipStream_t s
 extern "C" int prc_caf_execute_segments(prc_caf_plan* p, const void* ref, const void* srv,
                                         int64_t frame_stride, int64_t n_valid, const float* window,
                                         int32_t nframes, void* stream) {
+    PRC_RANGE("prc_caf_execute_segments");
     int rc = check_exec(p, nframes, "prc_caf_execute_segments");
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(p->mtx);
@@ -330,6 +331,7 @@ extern "C" int prc_caf_execute_segments(prc_caf_plan* p, const void* ref, const 
 }
 
 extern "C" int prc_caf_execute_doppler(prc_caf_plan* p, void* out, int32_t nframes, void* stream) {
+    PRC_RANGE("prc_caf_execute_doppler");
     int rc = check_exec(p, nframes, "prc_caf_execute_doppler");
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(p->mtx);
@@ -339,6 +341,7 @@ extern "C" int prc_caf_execute_doppler(prc_caf_plan* p, void* out, int32_t nfram
 extern "C" int prc_caf_execute(prc_caf_plan* p, const void* ref, const void* srv, int64_t frame_stride,
                                int64_t n_valid, const float* window, void* out, int32_t nframes,
                                void* stream) {
+    PRC_RANGE("prc_caf_execute");
     int rc = check_exec(p, nframes, "prc_caf_execute");
     if (rc) return rc;
     PRC_REQUIRE(out, PRC_EINVAL, "prc_caf_execute: null output");
@@ -359,6 +362,7 @@ extern "C" int prc_caf_execute(prc_caf_plan* p, const void* ref, const void* srv
 extern "C" int prc_caf_execute_multi(prc_caf_plan* p, const void* const* refs_host, int32_t nref, const void* srv,
                                      int64_t frame_stride, int64_t n_valid, const float* window,
                                      void* const* outs_host, int32_t nframes, void* stream) {
+    PRC_RANGE("prc_caf_execute_multi");
     PRC_REQUIRE(p && refs_host && outs_host && srv, PRC_EINVAL, "prc_caf_execute_multi: null argument");
     PRC_REQUIRE(nref >= 1 && nref <= PRC_CAF_MAX_REFS, PRC_EINVAL, "prc_caf_execute_multi: nref=%d outside [1, %d]",
                 nref, PRC_CAF_MAX_REFS);

@@ -11,12 +11,19 @@
 #define CF_TX 32
 #define CF_TY 8
 
-__global__ void cfar_abs_partial_kernel(const float* __restrict__ X, int64_t n, float* __restrict__ partial) {
+// The map comes in as magnitudes (float: CFAR_2D's own argument) or as the complex range-Doppler map itself (float2:
+// range_doppler_plot.py:56-57 calls CFAR_2D(np.abs(xambg), ...) -- |X| is then taken on the tile load, one read of the
+// complex map instead of an abs kernel's read + write and two reads of its result; np.abs of complex64 is hypotf).
+__device__ __forceinline__ float cfar_mag(float v) { return v; }
+__device__ __forceinline__ float cfar_mag(float2 v) { return hypotf(v.x, v.y); }
+
+template <typename TIn>
+__global__ void cfar_abs_partial_kernel(const TIn* __restrict__ X, int64_t n, float* __restrict__ partial) {
     __shared__ float red[256];
     const int f = blockIdx.y;
-    const float* x = X + (int64_t)f * n;
+    const TIn* x = X + (int64_t)f * n;
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += fabsf(x[i]);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += fabsf(cfar_mag(x[i]));
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -26,14 +33,15 @@ __global__ void cfar_abs_partial_kernel(const float* __restrict__ X, int64_t n, 
     if (threadIdx.x == 0) partial[(int64_t)f * gridDim.x + blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(CF_TX * CF_TY) void cfar_kernel(const float* __restrict__ X, int H, int W, int fw,
+template <typename TIn>
+__global__ __launch_bounds__(CF_TX * CF_TY) void cfar_kernel(const TIn* __restrict__ X, int H, int W, int fw,
                                                              int e1, int e2, float inv_cells,
                                                              const float* __restrict__ partial, int npartial,
                                                              float thresh, int use_thresh, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* tile = reinterpret_cast<float*>(smem_raw);        // (CF_TY + fw - 1) x (CF_TX + fw - 1)
     const int f = blockIdx.z;
-    const float* x = X + (int64_t)f * H * W;
+    const TIn* x = X + (int64_t)f * H * W;
     const int c = (fw - 1) / 2;
     const int th = CF_TY + fw - 1, tw = CF_TX + fw - 1;
     const int i0 = blockIdx.y * CF_TY, j0 = blockIdx.x * CF_TX;
@@ -44,7 +52,7 @@ __global__ __launch_bounds__(CF_TX * CF_TY) void cfar_kernel(const float* __rest
         int ii = (ib + r) % H, jj = (jb + s) % W;
         if (ii < 0) ii += H;
         if (jj < 0) jj += W;
-        tile[t] = x[(int64_t)ii * W + jj];
+        tile[t] = cfar_mag(x[(int64_t)ii * W + jj]);
     }
     float tot = 0.f;
     for (int k = 0; k < npartial; ++k) tot += partial[(int64_t)f * npartial + k];
@@ -77,7 +85,8 @@ __global__ __launch_bounds__(CF_TX * CF_TY) void cfar_kernel(const float* __rest
 // workgroup; the wrap-around indices are advanced, not divided.
 #define CS_TX 64
 #define CS_TY 16
-__global__ __launch_bounds__(256) void cfar_sep_kernel(const float* __restrict__ X, int H, int W, int fw, int e1, int e2,
+template <typename TIn>
+__global__ __launch_bounds__(256) void cfar_sep_kernel(const TIn* __restrict__ X, int H, int W, int fw, int e1, int e2,
                                                        float inv_cells, const float* __restrict__ partial, int npartial,
                                                        float thresh, int use_thresh, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(256) void cfar_sep_kernel(const float* __restrict__
     float* Ho = tile + th * twp;                             // th x CS_TX
     float* Hf = Ho + th * CS_TX;
     const int f = blockIdx.z;
-    const float* x = X + (int64_t)f * H * W;
+    const TIn* x = X + (int64_t)f * H * W;
     const int c = (fw - 1) / 2;
     const int i0 = blockIdx.y * CS_TY, j0 = blockIdx.x * CS_TX;
     const int tx = threadIdx.x & 63, tq = threadIdx.x >> 6;
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(256) void cfar_sep_kernel(const float* __restrict__
         if (jj < 0) jj += W;
         const int sstep = 64 % W;
         for (int s_ = tx; s_ < tw; s_ += 64) {
-            tile[r * twp + s_] = x[(int64_t)ii * W + jj];
+            tile[r * twp + s_] = cfar_mag(x[(int64_t)ii * W + jj]);
             jj += sstep;
             if (jj >= W) jj -= W;
         }
@@ -136,8 +145,9 @@ __global__ __launch_bounds__(256) void cfar_sep_kernel(const float* __restrict__
     }
 }
 
-extern "C" int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int32_t gw, int32_t use_thresh,
-                          float thresh, float* out, int32_t nframes, void* stream_) {
+template <typename TIn>
+static int cfar_run(const TIn* X, int32_t H, int32_t W, int32_t fw, int32_t gw, int32_t use_thresh,
+                    float thresh, float* out, int32_t nframes, void* stream_) {
     PRC_REQUIRE(X && out, PRC_EINVAL, "prc_cfar2d: null argument");
     PRC_REQUIRE(H > 0 && W > 0 && fw > 0 && gw >= 0 && nframes > 0, PRC_EINVAL, "prc_cfar2d: bad size");
     PRC_REQUIRE(fw * fw != gw * gw, PRC_EINVAL, "prc_cfar2d: fw^2 == gw^2 divides by zero (as in the reference)");
@@ -188,7 +198,7 @@ extern "C" int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int3
         sc.cap = need;
     }
     float* d_partial = sc.p;
-    hipLaunchKernelGGL(cfar_abs_partial_kernel, dim3(np, nframes), dim3(256), 0, stream, X, (int64_t)H * W, d_partial);
+    hipLaunchKernelGGL(cfar_abs_partial_kernel<TIn>, dim3(np, nframes), dim3(256), 0, stream, X, (int64_t)H * W, d_partial);
     int e1 = (fw - gw) / 2, e2 = fw - e1 + 1;
     if (e1 < 0) e1 = 0;
     if (e2 > fw) e2 = fw;
@@ -197,16 +207,28 @@ extern "C" int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int3
     const size_t lds_sep = sizeof(float) * (th * twp + 2 * th * CS_TX);
     if (lds_sep <= 64 * 1024 && prc_opt(PRC_OPT_CFAR_METHOD) != 1) {
         dim3 grid((W + CS_TX - 1) / CS_TX, (H + CS_TY - 1) / CS_TY, nframes);
-        hipLaunchKernelGGL(cfar_sep_kernel, grid, dim3(256), lds_sep, stream, X, H, W, fw, e1, e2, inv_cells, d_partial, np,
+        hipLaunchKernelGGL(cfar_sep_kernel<TIn>, grid, dim3(256), lds_sep, stream, X, H, W, fw, e1, e2, inv_cells, d_partial, np,
                            thresh, use_thresh, out);
     } else {
         const size_t lds = sizeof(float) * (size_t)(CF_TY + fw - 1) * (CF_TX + fw - 1);
         PRC_REQUIRE(lds <= 64 * 1024, PRC_EUNSUPPORTED, "prc_cfar2d: kernel width %d too large", fw);
         dim3 grid((W + CF_TX - 1) / CF_TX, (H + CF_TY - 1) / CF_TY, nframes);
-        hipLaunchKernelGGL(cfar_kernel, grid, dim3(CF_TX * CF_TY), lds, stream, X, H, W, fw, e1, e2, inv_cells, d_partial, np,
+        hipLaunchKernelGGL(cfar_kernel<TIn>, grid, dim3(CF_TX * CF_TY), lds, stream, X, H, W, fw, e1, e2, inv_cells, d_partial, np,
                            thresh, use_thresh, out);
     }
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { prc_set_error("prc_cfar2d: launch failed: %s", hipGetErrorString(le)); return PRC_EHIP; }
     return PRC_OK;
+}
+
+extern "C" int prc_cfar2d(const float* X, int32_t H, int32_t W, int32_t fw, int32_t gw, int32_t use_thresh,
+                          float thresh, float* out, int32_t nframes, void* stream) {
+    PRC_RANGE("prc_cfar2d");
+    return cfar_run<float>(X, H, W, fw, gw, use_thresh, thresh, out, nframes, stream);
+}
+
+extern "C" int prc_cfar2d_c64(const void* X, int32_t H, int32_t W, int32_t fw, int32_t gw, int32_t use_thresh,
+                              float thresh, float* out, int32_t nframes, void* stream) {
+    PRC_RANGE("prc_cfar2d_c64");
+    return cfar_run<float2>((const float2*)X, H, W, fw, gw, use_thresh, thresh, out, nframes, stream);
 }

@@ -46,6 +46,15 @@ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b;
 int prc_lds_optin(const void* kernel, int bytes);
 // current value of a prc_option (util.hip); plans read it once, at creation
 int64_t prc_opt(int option);
+// roctx range around an entry point when PRC_OPT_MARKERS is on (util.hip); otherwise one relaxed atomic load
+struct PrcRange {
+    bool on;
+    explicit PrcRange(const char* name);
+    ~PrcRange();
+    PrcRange(const PrcRange&) = delete;
+    PrcRange& operator=(const PrcRange&) = delete;
+};
+#define PRC_RANGE(name) PrcRange prc_range__(name)
 
 // ---- device-side complex helpers (float2 = complex64, double2 = complex128) ----
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {

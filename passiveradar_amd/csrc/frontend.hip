@@ -475,6 +475,7 @@ extern "C" int prc_frontend_out_len(const prc_frontend_plan* p, int64_t* n_out) 
 extern "C" int prc_frontend_execute(prc_frontend_plan* p, const void* raw, int64_t raw_stride, int32_t mix,
                                     double fc, double fs, const double* phases_host, void* out,
                                     int64_t out_stride, int32_t nblocks, void* stream_) {
+    PRC_RANGE("prc_frontend_execute");
     PRC_REQUIRE(p && raw && out, PRC_EINVAL, "prc_frontend_execute: null argument");
     PRC_REQUIRE(nblocks > 0 && nblocks <= p->desc.max_blocks, PRC_EINVAL,
                 "prc_frontend_execute: nblocks=%d outside [1, %d]", nblocks, p->desc.max_blocks);
@@ -563,6 +564,7 @@ __global__ void deinterleave_kernel(const void* raw, float2* out, int64_t n) {
 }
 
 extern "C" int prc_deinterleave(const void* raw, int32_t raw_dtype, int64_t n_complex, void* out, void* stream) {
+    PRC_RANGE("prc_deinterleave");
     PRC_REQUIRE(raw && out && n_complex > 0, PRC_EINVAL, "prc_deinterleave: bad argument");
     int64_t blocks = ceil_div64(n_complex, 256);
     if (blocks > 4096) blocks = 4096;
@@ -593,6 +595,7 @@ __global__ void freq_shift_block_kernel(const float2* __restrict__ x, double2* _
 
 extern "C" int prc_frequency_shift_block(const void* x, void* y, int64_t n, double fc, double fs,
                                          double block_phase, void* stream) {
+    PRC_RANGE("prc_frequency_shift_block");
     PRC_REQUIRE(x && y && n > 0 && fs != 0.0, PRC_EINVAL, "prc_frequency_shift_block: bad argument");
     PhaseRamp pr;
     pr.a32 = (float)(2.0 * 3.14159265358979323846 * fc);
@@ -632,6 +635,7 @@ __global__ void freq_shift_phases_kernel(const float2* __restrict__ x, void* __r
 
 extern "C" int prc_frequency_shift_phases(const void* x, void* y, int64_t n, double fc, double fs,
                                           const void* phases, int32_t phases_f32, void* stream) {
+    PRC_RANGE("prc_frequency_shift_phases");
     PRC_REQUIRE(x && y && phases && n > 0 && fs != 0.0, PRC_EINVAL, "prc_frequency_shift_phases: bad argument");
     PhaseRamp pr;
     pr.a32 = (float)(2.0 * 3.14159265358979323846 * fc);

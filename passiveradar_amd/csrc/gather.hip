@@ -148,6 +148,7 @@ extern "C" int prc_comm_destroy(prc_comm* c) {
 }
 
 extern "C" int prc_comm_loopback(prc_comm* c, const void* send, void* recv, int64_t nfloats, void* stream_) {
+    PRC_RANGE("prc_comm_loopback");
     PRC_REQUIRE(c && send && recv && nfloats > 0, PRC_EINVAL, "prc_comm_loopback: null argument or empty message");
     hipStream_t stream = (hipStream_t)stream_;
     std::lock_guard<std::mutex> lk(c->mtx);
@@ -180,6 +181,7 @@ extern "C" int prc_comm_loopback(prc_comm* c, const void* send, void* recv, int6
 //    deadlock RCCL warns about).
 extern "C" int prc_gather_frames(prc_comm* c, const void* send, const int64_t* frames_per_rank_host,
                                  int64_t frame_elems, void* recv, int32_t root, void* stream_) {
+    PRC_RANGE("prc_gather_frames");
     PRC_REQUIRE(c && frames_per_rank_host, PRC_EINVAL, "prc_gather_frames: null argument");
     PRC_REQUIRE(frame_elems > 0 && root >= 0 && root < c->world, PRC_EINVAL,
                 "prc_gather_frames: bad frame size or root %d", root);

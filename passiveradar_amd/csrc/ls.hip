@@ -1177,6 +1177,7 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
                               void* out, int64_t out_stride, int32_t nblocks, double sample_rate,
                               const double* bins, int32_t nbins, double reg, void* taps_out,
                               void* stream_) {
+    PRC_RANGE("prc_ls_execute");
     PRC_REQUIRE(p && ref && srv && out && bins, PRC_EINVAL, "prc_ls_execute: null argument");
     PRC_REQUIRE(nblocks > 0 && nblocks <= p->desc.max_blocks, PRC_EINVAL,
                 "prc_ls_execute: nblocks=%d outside [1, %d]", nblocks, p->desc.max_blocks);
@@ -1327,6 +1328,7 @@ __global__ void xcorr_reduce_kernel(const float2* __restrict__ partial, int nblk
 
 extern "C" int prc_xcorr(const void* s1, const void* s2, int64_t n, int32_t nlead, int32_t nlag,
                          void* out, void* stream_) {
+    PRC_RANGE("prc_xcorr");
     PRC_REQUIRE(s1 && s2 && out, PRC_EINVAL, "prc_xcorr: null argument");
     PRC_REQUIRE(n > 0 && nlead >= 0 && nlag >= 0, PRC_EINVAL, "prc_xcorr: bad size");
     // lags beyond the signal length are legal (signal_utils.py:29-32 pads s2 by nlag / nlead zeros): their sums are 0
@@ -1377,6 +1379,7 @@ __global__ void freq_shift_kernel(const float2* __restrict__ x, float2* __restri
 
 extern "C" int prc_frequency_shift(const void* x, void* y, int64_t n, double fc, double fs,
                                    double phase_offset, void* stream) {
+    PRC_RANGE("prc_frequency_shift");
     PRC_REQUIRE(x && y, PRC_EINVAL, "prc_frequency_shift: null argument");
     PRC_REQUIRE(n > 0 && fs != 0.0, PRC_EINVAL, "prc_frequency_shift: bad size or rate");
     PhaseRamp pr = make_ramp(fc, fs, phase_offset);

@@ -289,6 +289,7 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
                                 int32_t filter_len, int32_t peek, float mu, const void* taps_in,
                                 void* out, int64_t out_stride, void* taps_out, int32_t nstreams,
                                 void* stream) {
+    PRC_RANGE("prc_nlms_execute");
     PRC_REQUIRE(ref && srv && out, PRC_EINVAL, "prc_nlms_execute: null argument");
     PRC_REQUIRE(n > 0 && filter_len > 0 && peek >= 0 && nstreams > 0, PRC_EINVAL,
                 "prc_nlms_execute: non-positive size");

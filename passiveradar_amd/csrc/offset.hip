@@ -249,6 +249,7 @@ static int64_t filt_len(int64_t n, const prc_iir_desc* d) {
 }
 
 extern "C" int prc_decimate_iir(const void* x, int64_t n, const prc_iir_desc* iir, void* y, void* stream) {
+    PRC_RANGE("prc_decimate_iir");
     IirDev f;
     int rc = check_iir(iir, &f);
     if (rc) return rc;
@@ -269,6 +270,7 @@ extern "C" int prc_decimate_iir(const void* x, int64_t n, const prc_iir_desc* ii
 
 extern "C" int prc_channel_offset(const void* s1, int64_t n1, const void* s2, int64_t n2, const prc_iir_desc* iir,
                                   int64_t nl, float* xc_out, int64_t* n_xc, int64_t* argmax_out, void* stream) {
+    PRC_RANGE("prc_channel_offset");
     IirDev f;
     int rc = check_iir(iir, &f);
     if (rc) return rc;

@@ -30,12 +30,43 @@ int prc_lds_optin(const void* kernel, int bytes) {
     return PRC_OK;
 }
 
+// ---- roctx ranges (PRC_OPT_MARKERS): the marker library is bound at run time, only when the option is switched on ----
+#include <dlfcn.h>
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+static roctx_push_fn g_roctx_push = nullptr;
+static roctx_pop_fn g_roctx_pop = nullptr;
+static std::atomic<int> g_markers{0};
+static bool roctx_bind() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            roctx_push_fn push = (roctx_push_fn)dlsym(h, "roctxRangePushA");
+            roctx_pop_fn pop = (roctx_pop_fn)dlsym(h, "roctxRangePop");
+            if (push && pop) {
+                g_roctx_push = push;
+                g_roctx_pop = pop;
+                return;
+            }
+        }
+    });
+    return g_roctx_push != nullptr;
+}
+PrcRange::PrcRange(const char* name) : on(g_markers.load(std::memory_order_relaxed) != 0) {
+    if (on) (void)g_roctx_push(name);
+}
+PrcRange::~PrcRange() {
+    if (on) (void)g_roctx_pop();
+}
+
 // ---- tuning options (prcore.h: prc_option).  Process-wide values; plans copy what concerns them at creation. ----
 static std::atomic<int64_t> g_opt[PRC_OPT_COUNT_];
 static const int64_t g_opt_default[PRC_OPT_COUNT_] = {
     /* CAF_MULTI_MODE */ PRC_CAF_MULTI_AUTO, /* CAF_GROUP_MB */ 0, /* LS_TEAM_PIECES */ 32, /* LS_TEAM_ALIGN */ 1,
     /* NLMS_WAVES */ 0, /* LS_CACHE_LIMIT_MB */ 0, /* NLMS_WG_WAVES */ 0, /* CAF_XCD_CONTIG */ 0, /* CAF_PAIR_FRAMES */ 1,
-    /* FE_METHOD */ 0, /* CFAR_METHOD */ 0};
+    /* FE_METHOD */ 0, /* CFAR_METHOD */ 0, /* MARKERS */ 0};
 static std::once_flag g_opt_once;
 static void opt_init() {
     std::call_once(g_opt_once, [] { for (int i = 0; i < PRC_OPT_COUNT_; ++i) g_opt[i].store(g_opt_default[i]); });
@@ -60,9 +91,17 @@ extern "C" int prc_set_option(int32_t option, int64_t value) {
         case PRC_OPT_CAF_PAIR_FRAMES: ok = value == 0 || value == 1; break;
         case PRC_OPT_FE_METHOD: ok = value >= 0 && value <= 2; break;
         case PRC_OPT_CFAR_METHOD: ok = value == 0 || value == 1; break;
+        case PRC_OPT_MARKERS:
+            ok = value == 0 || value == 1;
+            if (value == 1 && !roctx_bind()) {
+                prc_set_error("prc_set_option: PRC_OPT_MARKERS needs librocprofiler-sdk-roctx.so.1 or libroctx64.so.4");
+                return PRC_EUNSUPPORTED;
+            }
+            break;
     }
     PRC_REQUIRE(ok, PRC_EINVAL, "prc_set_option: value %lld out of range for option %d", (long long)value, option);
     g_opt[option].store(value);
+    if (option == PRC_OPT_MARKERS) g_markers.store((int)value);
     return PRC_OK;
 }
 extern "C" int prc_get_option(int32_t option, int64_t* value) {
@@ -90,6 +129,12 @@ extern "C" int prc_set_device(int device) {
 extern "C" int prc_get_device(int* device) {
     PRC_REQUIRE(device, PRC_EINVAL, "prc_get_device: null argument");
     PRC_HIP(hipGetDevice(device));
+    return PRC_OK;
+}
+
+extern "C" int prc_mem_info(size_t* free_bytes, size_t* total_bytes) {
+    PRC_REQUIRE(free_bytes && total_bytes, PRC_EINVAL, "prc_mem_info: null argument");
+    PRC_HIP(hipMemGetInfo(free_bytes, total_bytes));
     return PRC_OK;
 }
 
