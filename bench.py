@@ -579,10 +579,15 @@ def main():
     ap.add_argument("--shard-of", default=None, metavar="RANK/WORLD",
                     help="cfg4 on ONE GPU: process only the shard rank RANK of WORLD would own (its frames + the two halo "
                          "chunks), no gather -- what one rank of an N-GPU run computes, measurable on a 1-GPU box")
+    ap.add_argument("--markers", action="store_true",
+                    help="PRC_OPT_MARKERS: the library's entry points open roctx ranges (rocprofv3 --marker-trace)")
     ap.add_argument("--dump", default=None, metavar="NPZ",
                     help="single GPU: save the maps of the last timed step's first, second, middle and last frame "
                          "(+ every frame's sum) so a test can hold the benchmarked path against an independent pass")
     args = ap.parse_args()
+    if args.markers:
+        from passiveradar_amd import _lib as _l
+        _l.set_option(_l.OPT_MARKERS, 1)
     if args.workload == "prconfig":
         return prconfig_main(args)
 

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "liboracle.so")
+_PATH = os.environ.get("ORACLE_LIB", os.path.join(_HERE, "liboracle.so"))    # ORACLE_LIB: the sanitizer build (make ASAN=1)
 _lib = None
 
 
