@@ -268,6 +268,13 @@ int prc_frontend_out_len(const prc_frontend_plan* plan, int64_t* n_out);   /* ce
 int prc_frontend_execute(prc_frontend_plan* plan, const void* raw, int64_t raw_stride, int32_t mix,
                          double fc, double fs, const double* phases_host, void* out, int64_t out_stride,
                          int32_t nblocks, void* stream);
+/* The same for BOTH channels of every block in one launch (main.py:133-149 tunes the reference and the surveillance
+ * recording with the same frequency and the same block phases): raw_a / raw_b and out_a / out_b share the strides and
+ * the phases; one rotation factor per input sample serves the two channels.  Results are bit-identical to two
+ * prc_frontend_execute calls.  Ratios the group kernel does not carry run the channels one after the other. */
+int prc_frontend_execute2(prc_frontend_plan* plan, const void* raw_a, const void* raw_b, int64_t raw_stride,
+                          int32_t mix, double fc, double fs, const double* phases_host, void* out_a, void* out_b,
+                          int64_t out_stride, int32_t nblocks, void* stream);
 /* deinterleave_IQ alone: n_complex pairs of raw scalars -> complex64 */
 int prc_deinterleave(const void* raw, int32_t raw_dtype, int64_t n_complex, void* out, void* stream);
 /* frequency_shift with an array (per-block) phase offset: complex64 in, complex128 out, float32 ramp

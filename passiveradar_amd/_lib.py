@@ -105,6 +105,8 @@ _SIGNATURES = {
     "prc_frontend_out_len": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "prc_frontend_execute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_double,
                                        C.POINTER(C.c_double), C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "prc_frontend_execute2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_double,
+                                        C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "prc_deinterleave": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "prc_frequency_shift_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                             C.c_double, C.c_void_p]),

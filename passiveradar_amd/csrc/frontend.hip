@@ -27,6 +27,8 @@
 struct FeArgs {
     const void* raw;
     float2* out;
+    const void* raw2;         // second channel of the same blocks (two-channel group kernel), tuned with the SAME phase
+    float2* out2;
     const float* taps;        // [J][up] polyphase layout: taps[j*up + p] = h[p + up*j]
     const double* phases;     // per block phase offset (device), or nullptr
     int64_t raw_stride;       // elements of the raw type between blocks (complex elements for C64)
@@ -92,15 +94,24 @@ __device__ __forceinline__ v2f fe_sincos(double x) {     // (cos x, sin x)
 
 // tuned sample i of the block (reference: complex128 after the array phase offset; rounded to float32 here, the
 // type the resampler's FIR runs in)
-template <int MIX = -1>     // 1: rotate, 0: do not, -1: a.mix decides (a wave-uniform branch per sample)
-__device__ __forceinline__ float2 fe_rotate(const FeArgs& a, float2 v, int64_t i, double blk_phase) {
-    if (MIX == 0 || (MIX < 0 && !a.mix)) return v;
+// The rotation factor of sample i (it depends on the sample index and the block phase only: main.py:133-149 tunes the
+// reference and the surveillance recording with the same phases, so two channels of a block share it) ...
+__device__ __forceinline__ v2f fe_twiddle(const FeArgs& a, int64_t i, double blk_phase) {
     const float ph32 = (a.pr.a32 * (float)(int)i) * a.pr.rcp32;  // float32 ramp, as the reference (n_in < 2^31: plan creation)
-    const v2f t = fe_sincos((double)ph32 + blk_phase), x = v2f{v.x, v.y};
-    v2f p, d;                                                    // x t = (x.x t.x - x.y t.y, x.y t.x + x.x t.y)
+    return fe_sincos((double)ph32 + blk_phase);
+}
+// ... and its product with a sample: x t = (x.x t.x - x.y t.y, x.y t.x + x.x t.y)
+__device__ __forceinline__ float2 fe_apply(float2 v, v2f t) {
+    const v2f x = v2f{v.x, v.y};
+    v2f p, d;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p) : "v"(x), "v"(t));
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(x), "v"(t), "v"(p));
     return make_float2(d.x, d.y);
+}
+template <int MIX = -1>     // 1: rotate, 0: do not, -1: a.mix decides (a wave-uniform branch per sample)
+__device__ __forceinline__ float2 fe_rotate(const FeArgs& a, float2 v, int64_t i, double blk_phase) {
+    if (MIX == 0 || (MIX < 0 && !a.mix)) return v;
+    return fe_apply(v, fe_twiddle(a, i, blk_phase));
 }
 template <int SRC>
 __device__ __forceinline__ float2 fe_tuned(const FeArgs& a, const void* raw, int64_t i, double blk_phase) {
@@ -205,7 +216,8 @@ typedef float __attribute__((address_space(4))) fe_const_float;
 struct FegArgs {
     const float* T;      // [FEG_WAVES * rows_per_wave][16]
     int32_t rows_per_wave, r_first;   // r_first: input offset r of the window's first sample (= r_hi - (FEG_WAVES rows_per_wave - 1))
-    int32_t lane_stride, pad, span;   // span: staged samples per workgroup
+    int32_t lane_stride, pad, span;   // span: staged samples per workgroup (and channel)
+    int32_t xstride;                  // two-channel form: LDS elements between the two channels' windows
     float inv_dn;
 };
 
@@ -226,99 +238,134 @@ __device__ __forceinline__ int feg_at(const FeArgs& a, const FegArgs& g, int k) 
 // FEG_CHUNK samples without a branch, so the compiler interleaves the eight rotation chains; the last, partial trip and
 // the two windows that touch a block end (the 'line' extension) take the general form below (clamped indices, every
 // choice a wave-uniform branch).
-template <int SRC>
-__device__ __forceinline__ void feg_stage_general(const FeArgs& a, const FegArgs& g, float2* X, const void* raw, int64_t i_w,
+template <int SRC, int NCH>
+__device__ __forceinline__ void feg_stage_general(const FeArgs& a, const FegArgs& g, float2* X, const void* const (&raw)[NCH], int64_t i_w,
                                                   double blk_phase, int k_first, bool edge) {
-    FeLine line;
-    if (edge) line = fe_line<SRC>(a, raw, blk_phase);
+    FeLine line[NCH];
+    if (edge) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) line[ch] = fe_line<SRC>(a, raw[ch], blk_phase);
+    }
     const int last = g.span - 1;
     for (int k0 = k_first; k0 <= last; k0 += FEG_THREADS * FEG_CHUNK) {
-        float2 v[FEG_CHUNK];
+        float2 v[NCH][FEG_CHUNK];
 #pragma unroll
         for (int c = 0; c < FEG_CHUNK; ++c) {
             int64_t i = i_w + min(k0 + c * FEG_THREADS, last);
             if (edge) i = i < 0 ? 0 : (i >= a.n_in ? a.n_in - 1 : i);
-            v[c] = fe_load<SRC>(raw, i);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) v[ch][c] = fe_load<SRC>(raw[ch], i);
         }
 #pragma unroll
         for (int c = 0; c < FEG_CHUNK; ++c) {
             const int k = k0 + c * FEG_THREADS;
             const int64_t i = i_w + k;
-            float2 t = fe_rotate<-1>(a, v[c], i, blk_phase);
-            if (edge) {
-                if (i < 0) t = make_float2((float)(line.x0.x + (double)i * line.slope.x), (float)(line.x0.y + (double)i * line.slope.y));
-                else if (i >= a.n_in) {
-                    const double d = (double)(i - (a.n_in - 1));
-                    t = make_float2((float)(line.xl.x + d * line.slope.x), (float)(line.xl.y + d * line.slope.y));
+            v2f tw = v2f{1.f, 0.f};
+            if (a.mix) tw = fe_twiddle(a, i, blk_phase);
+            const int at = feg_at<-1>(a, g, min(k, last));
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                float2 t = a.mix ? fe_apply(v[ch][c], tw) : v[ch][c];
+                if (edge) {
+                    const FeLine& ln = line[ch];
+                    if (i < 0) t = make_float2((float)(ln.x0.x + (double)i * ln.slope.x), (float)(ln.x0.y + (double)i * ln.slope.y));
+                    else if (i >= a.n_in) {
+                        const double d = (double)(i - (a.n_in - 1));
+                        t = make_float2((float)(ln.xl.x + d * ln.slope.x), (float)(ln.xl.y + d * ln.slope.y));
+                    }
                 }
+                if (k <= last) X[ch * g.xstride + at] = t;
             }
-            if (k <= last) X[feg_at<-1>(a, g, k)] = t;
         }
     }
 }
-template <int SRC, int PAD, int MIX>
-__device__ __forceinline__ void feg_stage_interior(const FeArgs& a, const FegArgs& g, float2* X, const void* raw, int64_t i_w,
+template <int SRC, int PAD, int MIX, int NCH>
+__device__ __forceinline__ void feg_stage_interior(const FeArgs& a, const FegArgs& g, float2* X, const void* const (&raw)[NCH], int64_t i_w,
                                                    double blk_phase, int tid) {
     // whole trips: the same number for every thread (a per-thread bound lets the first lanes of the workgroup take one trip
     // more than the rest: two of its wavefronts then run both forms, and everybody waits for them at the barrier)
     const int nfull = g.span / (FEG_THREADS * FEG_CHUNK);
     int k0 = tid;
     for (int trip = 0; trip < nfull; ++trip, k0 += FEG_THREADS * FEG_CHUNK) {
-        float2 v[FEG_CHUNK];
+        float2 v[NCH][FEG_CHUNK];
 #pragma unroll
-        for (int c = 0; c < FEG_CHUNK; ++c) v[c] = fe_load<SRC>(raw, i_w + k0 + c * FEG_THREADS);
+        for (int c = 0; c < FEG_CHUNK; ++c) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) v[ch][c] = fe_load<SRC>(raw[ch], i_w + k0 + c * FEG_THREADS);
+        }
         // the loads first, then everything that does not need them (the phases: most of the work) while they are in flight --
         // left alone the scheduler sinks the loads below the phase arithmetic
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < FEG_CHUNK; ++c) {
             const int k = k0 + c * FEG_THREADS;
+            const int at = feg_at<PAD>(a, g, k);
 #ifdef FEG_EXP_NOROT                  // timing ablation, never shipped: the staging without its rotations
-            X[feg_at<PAD>(a, g, k)] = v[c];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) X[ch * g.xstride + at] = v[ch][c];
 #else
-            X[feg_at<PAD>(a, g, k)] = fe_rotate<MIX>(a, v[c], i_w + k, blk_phase);
+            if (MIX) {
+                const v2f tw = fe_twiddle(a, i_w + k, blk_phase);      // ONE rotation factor for every channel of the block
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) X[ch * g.xstride + at] = fe_apply(v[ch][c], tw);
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) X[ch * g.xstride + at] = v[ch][c];
+            }
 #endif
         }
     }
-    feg_stage_general<SRC>(a, g, X, raw, i_w, blk_phase, k0, false);
+    feg_stage_general<SRC, NCH>(a, g, X, raw, i_w, blk_phase, k0, false);
 }
-template <int SRC>
-__device__ __forceinline__ void feg_stage(const FeArgs& a, const FegArgs& g, float2* X, const void* raw, int64_t i_w,
+template <int SRC, int NCH>
+__device__ __forceinline__ void feg_stage(const FeArgs& a, const FegArgs& g, float2* X, const void* const (&raw)[NCH], int64_t i_w,
                                           double blk_phase, int tid) {
-    if (i_w < 0 || i_w + g.span > a.n_in) feg_stage_general<SRC>(a, g, X, raw, i_w, blk_phase, tid, true);
+    if (i_w < 0 || i_w + g.span > a.n_in) feg_stage_general<SRC, NCH>(a, g, X, raw, i_w, blk_phase, tid, true);
     else if (g.pad) {
-        if (a.mix) feg_stage_interior<SRC, 1, 1>(a, g, X, raw, i_w, blk_phase, tid);
-        else feg_stage_interior<SRC, 1, 0>(a, g, X, raw, i_w, blk_phase, tid);
+        if (a.mix) feg_stage_interior<SRC, 1, 1, NCH>(a, g, X, raw, i_w, blk_phase, tid);
+        else feg_stage_interior<SRC, 1, 0, NCH>(a, g, X, raw, i_w, blk_phase, tid);
     } else {
-        if (a.mix) feg_stage_interior<SRC, 0, 1>(a, g, X, raw, i_w, blk_phase, tid);
-        else feg_stage_interior<SRC, 0, 0>(a, g, X, raw, i_w, blk_phase, tid);
+        if (a.mix) feg_stage_interior<SRC, 0, 1, NCH>(a, g, X, raw, i_w, blk_phase, tid);
+        else feg_stage_interior<SRC, 0, 0, NCH>(a, g, X, raw, i_w, blk_phase, tid);
     }
 }
 
-template <int NQ>
+// NCH = 2 (prc_frontend_execute2): both channels of a block in ONE workgroup.  A wavefront's lanes are 32 groups x 2
+// channels (lane = 32 channel + group): the window per channel is half as long (32 dn inputs + the rows), the two
+// windows together take the LDS one 64-group window took, and the row loop is the same instruction stream -- the taps are
+// wave-uniform whatever channel a lane reads.  What is saved is the staging: one rotation factor per input sample serves
+// both channels (31 of the ~40 instructions a staged sample costs).
+template <int NQ, int NCH>
 __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group_kernel(FeArgs a, FegArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* X = reinterpret_cast<float2*>(smem_raw);
+    constexpr int G = FEG_G / NCH;                                  // groups per workgroup
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
-    const void* raw = fe_block<FE_SRC_RT>(a, b);
+    const void* raw[NCH];
+    raw[0] = fe_block<FE_SRC_RT>(a, b);
+    if (NCH == 2) {
+        FeArgs a2 = a;
+        a2.raw = a.raw2;
+        raw[NCH - 1] = fe_block<FE_SRC_RT>(a2, b);
+    }
     const double blk_phase = (a.mix && a.phases) ? a.phases[b] : 0.0;
-    const int64_t N0 = (int64_t)blockIdx.x * FEG_G;                 // first group of the workgroup
+    const int64_t N0 = (int64_t)blockIdx.x * G;                     // first group of the workgroup
     const int64_t i_w = N0 * a.dn + g.r_first;                      // input index of the window's first sample
     switch (a.src) {            // one scalar branch per window, not per sample
-        case PRC_RAW_I8: feg_stage<PRC_RAW_I8>(a, g, X, raw, i_w, blk_phase, tid); break;
-        case PRC_RAW_U8: feg_stage<PRC_RAW_U8>(a, g, X, raw, i_w, blk_phase, tid); break;
-        case PRC_RAW_I16: feg_stage<PRC_RAW_I16>(a, g, X, raw, i_w, blk_phase, tid); break;
-        case PRC_RAW_F32: feg_stage<PRC_RAW_F32>(a, g, X, raw, i_w, blk_phase, tid); break;
-        default: feg_stage<PRC_RAW_C64>(a, g, X, raw, i_w, blk_phase, tid);
+        case PRC_RAW_I8: feg_stage<PRC_RAW_I8, NCH>(a, g, X, raw, i_w, blk_phase, tid); break;
+        case PRC_RAW_U8: feg_stage<PRC_RAW_U8, NCH>(a, g, X, raw, i_w, blk_phase, tid); break;
+        case PRC_RAW_I16: feg_stage<PRC_RAW_I16, NCH>(a, g, X, raw, i_w, blk_phase, tid); break;
+        case PRC_RAW_F32: feg_stage<PRC_RAW_F32, NCH>(a, g, X, raw, i_w, blk_phase, tid); break;
+        default: feg_stage<PRC_RAW_C64, NCH>(a, g, X, raw, i_w, blk_phase, tid);
     }
     __syncthreads();
     v2f acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = v2f{0.f, 0.f};
-    const float2* xl = X + lane * g.lane_stride;
+    const float2* xl = NCH == 2 ? X + (lane >> 5) * g.xstride + (lane & 31) * g.lane_stride : X + lane * g.lane_stride;
     const int row0 = w * g.rows_per_wave;
     // two rows per trip: 2 x 16 taps through the scalar unit, two inputs from LDS, 2 NQ packed multiply-adds.  A row's
     // input sits o = (rows - 1 - row) samples after the lane's first one (plus one pad sample per dn of them when dn is
@@ -365,20 +412,23 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
     for (int q = 0; q < NQ; ++q) P[(w * FEG_G + lane) * pitch + q] = make_float2(acc[q].x, acc[q].y);
     __syncthreads();
     const int64_t M0 = N0 * a.up;
-    float2* out = a.out + (int64_t)b * a.out_stride;
-    for (int o = tid; o < FEG_G * a.up; o += FEG_THREADS) {
-        const int64_t m = M0 + o;
-        if (m >= a.n_out) break;
-        const int n = o / a.up, q = o - n * a.up;
-        const int at = n * pitch + q;
-        float2 sum = P[at];
 #pragma unroll
-        for (int v = 1; v < FEG_WAVES; ++v) {                       // wavefront 0's rows first, in order, every time
-            const float2 pv = P[v * FEG_G * pitch + at];
-            sum.x += pv.x;
-            sum.y += pv.y;
+    for (int ch = 0; ch < NCH; ++ch) {
+        float2* out = (ch ? a.out2 : a.out) + (int64_t)b * a.out_stride;
+        for (int o = tid; o < G * a.up; o += FEG_THREADS) {
+            const int64_t m = M0 + o;
+            if (m >= a.n_out) break;
+            const int n = o / a.up, q = o - n * a.up;
+            const int at = (ch * G + n) * pitch + q;
+            float2 sum = P[at];
+#pragma unroll
+            for (int v = 1; v < FEG_WAVES; ++v) {                   // wavefront 0's rows first, in order, every time
+                const float2 pv = P[v * FEG_G * pitch + at];
+                sum.x += pv.x;
+                sum.y += pv.y;
+            }
+            out[m] = sum;
         }
-        out[m] = sum;
     }
 }
 
@@ -389,6 +439,8 @@ struct prc_frontend_plan {
     float* d_T = nullptr;        // group form: tap rows (nullptr: up > 16 or the window does not fit LDS)
     FegArgs g = {};
     size_t g_lds = 0;
+    FegArgs g2 = {};             // two-channel form (32 groups per channel and workgroup); g2_lds = 0: not available
+    size_t g2_lds = 0;
     int J = 0;
     int64_t n_in = 0, n_out = 0;
     std::mutex mtx;
@@ -454,7 +506,19 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
             p->g.pad = pad;
             p->g.span = (int32_t)span;
             p->g.inv_dn = 1.0f / (float)dn;
+            p->g.xstride = 0;
             p->g_lds = lds;
+            // two channels per workgroup: 32 groups each, the two windows side by side
+            const int64_t span2 = dn * (FEG_G / 2 - 1) + FEG_WAVES * rpw;
+            const int64_t x2 = (span2 + pad * ((span2 - 1) / dn) + 1 + 1) & ~(int64_t)1;
+            size_t lds2 = sizeof(float2) * 2 * (size_t)x2;
+            if (lds2 < lds_p) lds2 = lds_p;
+            if (lds2 <= 78 * 1024) {
+                p->g2 = p->g;
+                p->g2.span = (int32_t)span2;
+                p->g2.xstride = (int32_t)x2;
+                p->g2_lds = lds2;
+            }
         }
     }
     if (e != hipSuccess) {
@@ -472,19 +536,20 @@ extern "C" int prc_frontend_out_len(const prc_frontend_plan* p, int64_t* n_out) 
     return PRC_OK;
 }
 
-extern "C" int prc_frontend_execute(prc_frontend_plan* p, const void* raw, int64_t raw_stride, int32_t mix,
-                                    double fc, double fs, const double* phases_host, void* out,
-                                    int64_t out_stride, int32_t nblocks, void* stream_) {
-    PRC_RANGE("prc_frontend_execute");
+static int frontend_run(prc_frontend_plan* p, const void* raw, const void* raw2, int64_t raw_stride, int32_t mix,
+                        double fc, double fs, const double* phases_host, void* out, void* out2,
+                        int64_t out_stride, int32_t nblocks, void* stream_) {
     PRC_REQUIRE(p && raw && out, PRC_EINVAL, "prc_frontend_execute: null argument");
     PRC_REQUIRE(nblocks > 0 && nblocks <= p->desc.max_blocks, PRC_EINVAL,
                 "prc_frontend_execute: nblocks=%d outside [1, %d]", nblocks, p->desc.max_blocks);
     PRC_REQUIRE(out_stride >= p->n_out, PRC_ESHAPE, "prc_frontend_execute: out_stride shorter than the output");
     hipStream_t stream = (hipStream_t)stream_;
-    std::lock_guard<std::mutex> lk(p->mtx);
+    std::unique_lock<std::mutex> lk(p->mtx);
     FeArgs a;
     a.raw = raw;
     a.out = (float2*)out;
+    a.raw2 = raw2;
+    a.out2 = (float2*)out2;
     a.taps = p->d_taps;
     a.phases = nullptr;
     if (mix && phases_host) {
@@ -510,17 +575,35 @@ extern "C" int prc_frontend_execute(prc_frontend_plan* p, const void* raw, int64
     PRC_REQUIRE(method != 2 || p->d_T, PRC_EUNSUPPORTED,
                 "prc_frontend_execute: the group form needs up <= 16 and a window of 64 down samples within 78 KB of LDS (up=%d, down=%d)",
                 a.up, a.dn);
+    const int nq = a.up <= 4 ? 4 : (a.up <= 8 ? 8 : (a.up <= 13 ? 13 : 16));   // accumulators per thread (the tap rows are zero beyond `up`)
+    if (raw2 && p->d_T && p->g2_lds && method != 1) {
+        // both channels of every block in one workgroup (one rotation factor per input sample for the two of them)
+        dim3 grid((unsigned)ceil_div64(p->n_out, (int64_t)(FEG_G / 2) * a.up), (unsigned)nblocks);
+#define PRC_FEG2_CASE(Q)                                                                             \
+    case Q:                                                                                          \
+        if (int rc_ = prc_lds_optin((const void*)frontend_group_kernel<Q, 2>, (int)p->g2_lds)) return rc_; \
+        hipLaunchKernelGGL((frontend_group_kernel<Q, 2>), grid, dim3(FEG_THREADS), p->g2_lds, stream, a, p->g2); \
+        break;
+        switch (nq) { PRC_FEG2_CASE(4) PRC_FEG2_CASE(8) PRC_FEG2_CASE(13) PRC_FEG2_CASE(16) }
+#undef PRC_FEG2_CASE
+        PRC_LAUNCH_CHECK();
+        return PRC_OK;
+    }
+    if (raw2) {
+        // no two-channel form for this ratio (or it was switched off): the channels one after the other, same phases
+        lk.unlock();
+        int rc = frontend_run(p, raw, nullptr, raw_stride, mix, fc, fs, phases_host, out, nullptr, out_stride, nblocks, stream_);
+        if (rc != PRC_OK) return rc;
+        return frontend_run(p, raw2, nullptr, raw_stride, mix, fc, fs, phases_host, out2, nullptr, out_stride, nblocks, stream_);
+    }
     if (p->d_T && method != 1) {
         dim3 grid((unsigned)ceil_div64(p->n_out, (int64_t)FEG_G * a.up), (unsigned)nblocks);
 #define PRC_FEG_CASE(Q)                                                                              \
     case Q:                                                                                          \
-        if (int rc_ = prc_lds_optin((const void*)frontend_group_kernel<Q>, (int)p->g_lds)) return rc_; \
-        hipLaunchKernelGGL(frontend_group_kernel<Q>, grid, dim3(FEG_THREADS), p->g_lds, stream, a, p->g);    \
+        if (int rc_ = prc_lds_optin((const void*)frontend_group_kernel<Q, 1>, (int)p->g_lds)) return rc_; \
+        hipLaunchKernelGGL((frontend_group_kernel<Q, 1>), grid, dim3(FEG_THREADS), p->g_lds, stream, a, p->g);    \
         break;
-        // accumulators per thread: the smallest of 4, 8, 13, 16 that holds `up` (the tap rows are zero beyond `up`)
-        switch (a.up <= 4 ? 4 : (a.up <= 8 ? 8 : (a.up <= 13 ? 13 : 16))) {
-            PRC_FEG_CASE(4) PRC_FEG_CASE(8) PRC_FEG_CASE(13) PRC_FEG_CASE(16)
-        }
+        switch (nq) { PRC_FEG_CASE(4) PRC_FEG_CASE(8) PRC_FEG_CASE(13) PRC_FEG_CASE(16) }
 #undef PRC_FEG_CASE
         PRC_LAUNCH_CHECK();
         return PRC_OK;
@@ -554,6 +637,21 @@ extern "C" int prc_frontend_execute(prc_frontend_plan* p, const void* raw, int64
 #undef PRC_FE_CASE
     PRC_LAUNCH_CHECK();
     return PRC_OK;
+}
+
+extern "C" int prc_frontend_execute(prc_frontend_plan* p, const void* raw, int64_t raw_stride, int32_t mix,
+                                    double fc, double fs, const double* phases_host, void* out,
+                                    int64_t out_stride, int32_t nblocks, void* stream) {
+    PRC_RANGE("prc_frontend_execute");
+    return frontend_run(p, raw, nullptr, raw_stride, mix, fc, fs, phases_host, out, nullptr, out_stride, nblocks, stream);
+}
+
+extern "C" int prc_frontend_execute2(prc_frontend_plan* p, const void* raw_a, const void* raw_b, int64_t raw_stride,
+                                     int32_t mix, double fc, double fs, const double* phases_host, void* out_a,
+                                     void* out_b, int64_t out_stride, int32_t nblocks, void* stream) {
+    PRC_RANGE("prc_frontend_execute2");
+    PRC_REQUIRE(raw_b && out_b, PRC_EINVAL, "prc_frontend_execute2: null second channel");
+    return frontend_run(p, raw_a, raw_b, raw_stride, mix, fc, fs, phases_host, out_a, out_b, out_stride, nblocks, stream);
 }
 
 // deinterleave_IQ alone (signal_utils.py:19-22): raw scalars -> complex64

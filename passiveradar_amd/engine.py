@@ -254,6 +254,18 @@ class FrontendPlan:
                                          int(bool(mix)), float(fc), float(fs), ph, _ptr(out),
                                          int(self.n_out if out_stride is None else out_stride), int(nblocks), stream))
 
+    def execute2(self, raw_a, raw_b, out_a, out_b, nblocks=1, raw_stride=None, out_stride=None, fc=0.0, fs=1.0,
+                 phases=None, mix=True, stream=None):
+        """prc_frontend_execute2: both channels of every block in one launch (same strides, same phases)"""
+        ph = None
+        if phases is not None:
+            ph = (C.c_double * nblocks)(*[float(p) for p in phases])
+        itemscalars = 1 if self.raw_is_complex else 2
+        check(lib().prc_frontend_execute2(self._h, _ptr(raw_a), _ptr(raw_b),
+                                          int(self.n_in * itemscalars if raw_stride is None else raw_stride),
+                                          int(bool(mix)), float(fc), float(fs), ph, _ptr(out_a), _ptr(out_b),
+                                          int(self.n_out if out_stride is None else out_stride), int(nblocks), stream))
+
     def close(self):
         if getattr(self, "_h", None):
             lib().prc_frontend_plan_destroy(self._h)

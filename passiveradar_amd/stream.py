@@ -366,7 +366,7 @@ class HipBackend:
     def __init__(self, cpi_samples, num_range_cells, num_doppler_cells, IF_sample_rate,
                  doppler_bins=(0, 1, -1, 2, -2), window=("kaiser", 5.0), clutter="ls",
                  batch=16, device=None, caf_method=0, doppler_method=0, nlms_mu=0.02, overlap=True,
-                 ls_method=0, nsub=1, ls_streams=3, nref=1, ls_reg=1.0, caf_multi="auto"):
+                 ls_method=0, nsub=1, ls_streams=3, nref=1, ls_reg=1.0, caf_multi="auto", caf_lanes=1):
         """clutter: "ls" = LS_Filter_Multiple over ``doppler_bins`` (main.py:169-176, the reference's choice),
         "ls_direct" = LS_Filter (clutter_removal.py:6-56: circular data matrix, ``ls_reg`` on the Gram diagonal, one
         bin -- SURVEY 8's config-2 "LS_Filter variant"), "nlms" = NLMS_filter with step ``nlms_mu``, None = no canceller."""
@@ -419,6 +419,17 @@ class HipBackend:
             self.s_caf = torch.cuda.Stream(device=self.device) if self.overlap else None
         self._clean_buf = None
         self._fe_plans = {}
+        # frames_multi in two lanes (config 5): alternate pieces of batch/2 frames go to two plans on two streams, so the
+        # Doppler kernel of one piece (issue-stalled on its LDS / memory instructions) runs under the segment kernel of the
+        # next (latency-bound) and no launch ramp or tail is exposed between the stages
+        self.caf_lanes = 2 if (int(caf_lanes) >= 2 and self.batch >= 2) else 1
+        self._lane_plans, self._lane_streams = [], []
+        if self.caf_lanes == 2:
+            with torch.cuda.device(self.device):
+                per = -(-self.batch // 2)
+                self._lane_plans = [engine.CafPlan(self.cpi, self.R, self.F, per * self.nref, caf_method, doppler_method,
+                                                   multi=caf_multi) for _ in range(2)]
+                self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
 
     def _stream(self):
         from . import _lib
@@ -439,12 +450,30 @@ class HipBackend:
         tensor, blocks concatenated).  One fused kernel per batch of blocks.  block0: index of the first block within
         its recording (the block phases of main.py:125-131 continue across calls on consecutive pieces of one recording);
         out: optional device tensor of nblocks * output_chunk_length complex64 to write into."""
+        return self._front_end((raw,), input_chunk_length, offset_freq, input_sample_rate, up, dn, max_blocks, block0,
+                               (out,))[0]
+
+    def front_end2(self, raw_ref, raw_srv, input_chunk_length, offset_freq, input_sample_rate, up, dn, max_blocks=32,
+                   block0=0, out_ref=None, out_srv=None):
+        """main.py:133-149: BOTH recordings through the front end in one launch per batch of blocks -- they are tuned
+        with the same frequency and the same block phases, so one rotation factor per input sample serves the two
+        (prc_frontend_execute2).  Same arguments as front_end; returns (ref IF stream, srv IF stream), bit-identical to
+        two front_end calls."""
+        return self._front_end((raw_ref, raw_srv), input_chunk_length, offset_freq, input_sample_rate, up, dn, max_blocks,
+                               block0, (out_ref, out_srv))
+
+    def _front_end(self, raws, input_chunk_length, offset_freq, input_sample_rate, up, dn, max_blocks, block0, outs):
         torch = self.torch
         from . import _lib
-        t = raw if torch.is_tensor(raw) else torch.from_numpy(np.ascontiguousarray(raw))
-        if str(t.dtype).replace("torch.", "") not in _lib.RAW_DTYPES:
-            t = t.to(torch.float32)
-        t = t.to(self.device, non_blocking=True).contiguous()
+        ts = []
+        for raw in raws:
+            t = raw if torch.is_tensor(raw) else torch.from_numpy(np.ascontiguousarray(raw))
+            if str(t.dtype).replace("torch.", "") not in _lib.RAW_DTYPES:
+                t = t.to(torch.float32)
+            ts.append(t.to(self.device, non_blocking=True).contiguous())
+        if len(ts) == 2 and (ts[0].dtype != ts[1].dtype or ts[0].shape != ts[1].shape):
+            raise ValueError("front_end2: the two recordings must have the same sample type and length")
+        t = ts[0]
         icl = int(input_chunk_length)
         nblocks = int(t.shape[0]) // icl
         n_in = icl // 2
@@ -456,9 +485,11 @@ class HipBackend:
                                                                       up, dn, max_blocks)
         per_block = n_in % (input_sample_rate // offset_freq)                       # main.py:125-130
         phases = 2 * np.pi * (np.arange(nblocks) + int(block0)) * per_block * (offset_freq / input_sample_rate)
-        if out is None:
-            out = torch.empty(nblocks * plan.n_out, dtype=torch.complex64, device=self.device)
-        else:
+        outs = list(outs)
+        for i, out in enumerate(outs):
+            if out is None:
+                outs[i] = torch.empty(nblocks * plan.n_out, dtype=torch.complex64, device=self.device)
+                continue
             # the kernel writes nblocks * n_out complex64 straight into the caller's tensor: anything else than a
             # contiguous complex64 tensor of at least that size on this device would be a silent out-of-bounds write
             if not (torch.is_tensor(out) and out.is_cuda and out.device == self.device):
@@ -471,9 +502,13 @@ class HipBackend:
         with torch.cuda.device(self.device):
             for b0 in range(0, nblocks, max_blocks):
                 nb = min(max_blocks, nblocks - b0)
-                plan.execute(t[b0 * icl:], out[b0 * plan.n_out:], nb, icl, plan.n_out, offset_freq,
-                             input_sample_rate, phases[b0:b0 + nb], True, self._stream())
-        return out
+                if len(ts) == 2:
+                    plan.execute2(ts[0][b0 * icl:], ts[1][b0 * icl:], outs[0][b0 * plan.n_out:], outs[1][b0 * plan.n_out:],
+                                  nb, icl, plan.n_out, offset_freq, input_sample_rate, phases[b0:b0 + nb], True, self._stream())
+                else:
+                    plan.execute(t[b0 * icl:], outs[0][b0 * plan.n_out:], nb, icl, plan.n_out, offset_freq,
+                                 input_sample_rate, phases[b0:b0 + nb], True, self._stream())
+        return tuple(outs)
 
     def _clean_target(self, srv_pad):
         # the cleaned stream buffer is reused across calls; only its two C/2 pads must be zero and
@@ -551,11 +586,16 @@ class HipBackend:
                     f_lo = stop
         return out
 
-    def frames_multi(self, ref_pads, clean_pad, offsets_first, nframes, outs=None, stream=None):
+    def frames_multi(self, ref_pads, clean_pad, offsets_first, nframes, outs=None, stream=None, join=True):
         """fast_xambg of EVERY reference channel in ``ref_pads`` against the one (cleaned) surveillance stream, frame
         by overlapped frame: a multi-illuminator frame (BASELINE config 5) through prc_caf_execute_multi, which
         transforms the surveillance pieces once per segment for all illuminators.  Returns one
-        [nframes][F][R+1] tensor per reference channel."""
+        [nframes][F][R+1] tensor per reference channel.
+
+        With ``caf_lanes=2`` (and no explicit ``stream``) pieces of batch/2 frames alternate between two plans on two
+        streams; the lanes start behind whatever the current stream holds, and ``join`` makes the current stream wait for
+        them at the end (join=False: the caller synchronises -- a resident pipeline whose next call may then start under
+        this call's last Doppler launch)."""
         torch = self.torch
         nref = len(ref_pads)
         if nref > self.nref:
@@ -563,6 +603,25 @@ class HipBackend:
         if outs is None:
             outs = [torch.empty((nframes, self.F, self.R + 1), dtype=torch.complex64, device=self.device)
                     for _ in ref_pads]
+        if self.caf_lanes == 2 and stream is None and nframes > 1:
+            import ctypes
+            main = torch.cuda.current_stream(self.device)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            per = -(-self.batch // 2)
+            with torch.cuda.device(self.device):
+                for i, f0 in enumerate(range(0, nframes, per)):
+                    st, plan = self._lane_streams[i & 1], self._lane_plans[i & 1]
+                    if i < 2:
+                        st.wait_event(ev)
+                    nb = min(per, nframes - f0)
+                    off = offsets_first + f0 * self.C
+                    plan.execute_multi([r[off:] for r in ref_pads], clean_pad[off:], [o[f0:] for o in outs], nb,
+                                       self.C, self.cpi, self.window, ctypes.c_void_p(st.cuda_stream))
+            if join:
+                for st in self._lane_streams:
+                    main.wait_stream(st)
+            return outs
         with torch.cuda.device(self.device):
             for f0 in range(0, nframes, self.batch):
                 nb = min(self.batch, nframes - f0)
@@ -670,8 +729,11 @@ class StreamProcessor:
         the LS + CAF pipeline.  ``config`` is the dict of passiveradar_amd.config.getConfiguration."""
         args = (config["input_chunk_length"], config["offset_freq"], config["input_sample_rate"],
                 config["resamp_up"], config["resamp_dn"])
-        ref = self.backend.front_end(raw_ref, *args)
-        srv = self.backend.front_end(raw_srv, *args)
+        if hasattr(self.backend, "front_end2") and np.shape(raw_ref) == np.shape(raw_srv):
+            ref, srv = self.backend.front_end2(raw_ref, raw_srv, *args)       # one launch per batch of blocks for both
+        else:
+            ref = self.backend.front_end(raw_ref, *args)
+            srv = self.backend.front_end(raw_srv, *args)
         return self.process(ref, srv, gather=gather)
 
     @staticmethod

@@ -8,7 +8,7 @@ from passiveradar_amd import scene
 from passiveradar_amd.clutter_removal import LS_Filter, LS_Filter_Multiple, LS_Filter_Toeplitz, NLMS_filter
 from passiveradar_amd.range_doppler_processing import fast_xambg, fast_xambg_multi
 from passiveradar_amd.signal_utils import decimate_iir, deinterleave_IQ, find_channel_offset, frequency_shift, front_end, resample, xcorr
-from passiveradar_amd.target_detection import CFAR_2D
+from passiveradar_amd.target_detection import CFAR_2D, CFAR_2D_abs
 
 import os, threading
 from passiveradar_amd import clutter_removal as _cr
@@ -34,13 +34,34 @@ def note(kind, err, tol, desc):
 def worker(wseed):
   rng = np.random.default_rng(wseed)
   while time.time() - t0 < budget:
-      k = rng.integers(0, 24) if KINDS is None else int(rng.choice(KINDS))
+      k = rng.integers(0, 26) if KINDS is None else int(rng.choice(KINDS))
       if k == 20:     # power-of-two Doppler bin counts: the column-FFT Doppler kernel (256 .. 4096), ragged column tiles
           F = int(rng.choice([256, 512, 1024, 2048, 4096])); q = int(rng.integers(4, 40)); N = F * q + int(rng.integers(0, F))
           R = int(rng.integers(1, min(700, N // 2 - 1)))
           ref, srv = scene.make_scene(N, 1e5, min(R, 200), int(rng.integers(1 << 30)))
           w = None if rng.random() < 0.5 else np.kaiser(N, 5.0)
           note("caf_column_doppler", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("cafcol", N, R, F, w is not None))
+      elif k == 24:   # CFAR of the complex map in one kernel (|X| on the tile load), either kernel form
+          H, W = int(rng.integers(3, 300)), int(rng.integers(3, 300)); fw = int(rng.integers(3, 19)); gw = int(rng.integers(0, fw - 1))
+          X = (rng.standard_normal((H, W)) + 1j * rng.standard_normal((H, W))).astype(np.complex64)
+          from passiveradar_amd import _lib
+          _lib.set_option(_lib.OPT_CFAR_METHOD, int(rng.integers(0, 2)))
+          try:
+              note("cfar_abs", rel(CFAR_2D_abs(X, fw, gw), O.CFAR_2D(np.abs(X), fw, gw)), 2e-5, ("cfarabs", H, W, fw, gw))
+          finally:
+              _lib.set_option(_lib.OPT_CFAR_METHOD, 0)
+      elif k == 25:   # both channels of a recording through the front end in one launch == one launch per channel, and the oracle
+          import torch
+          from math import gcd
+          from passiveradar_amd.stream import HipBackend
+          up, dn = int(rng.integers(1, 20)), int(rng.integers(2, 130)); nb = int(rng.integers(1, 6)); dt = str(rng.choice(["int8", "uint8", "int16", "float32"]))
+          n_in = int(rng.integers(2 * dn + 3, 20000)); foff = int(rng.choice([100000, 37500, 2400]))
+          if up // gcd(up, dn) != dn // gcd(up, dn):
+              ra, rb = ((rng.standard_normal(2 * n_in * nb) * 30).astype(dt) for _ in range(2))
+              be = HipBackend(4096, 8, 16, 2.6e5, batch=2, clutter=None)
+              a2, b2 = be.front_end2(ra, rb, 2 * n_in, foff, 2400000, up, dn, max_blocks=2)
+              same = torch.equal(a2, be.front_end(ra, 2 * n_in, foff, 2400000, up, dn, max_blocks=2)) and torch.equal(b2, be.front_end(rb, 2 * n_in, foff, 2400000, up, dn, max_blocks=2))
+              note("front_end2", max(rel(b2.cpu().numpy(), O.front_end(rb, 2 * n_in, foff, 2400000, up, dn)), 0.0 if same else 1.0), 2e-5, ("fe2", n_in, dt, up, dn, nb, foff))
       elif k == 22:   # xcorr of two signals of different lengths (signal_utils.py:29-32 accepts any two)
           n1, n2 = int(rng.integers(1, 30000)), int(rng.integers(1, 30000)); nlead = int(rng.integers(0, 60)); nlag = int(rng.integers(0, 300))
           a = scene.white_reference(n1, int(rng.integers(1 << 30))); b = scene.white_reference(n2, int(rng.integers(1 << 30)))

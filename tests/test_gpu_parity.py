@@ -1078,3 +1078,77 @@ def test_cfar_kernel_forms_agree(H, W, fw, gw):
         assert (det[0] != det[1]).mean() < 1e-3                   # cells within a rounding of the threshold may flip
     finally:
         _lib.set_option(_lib.OPT_CFAR_METHOD, old)
+
+
+@pytest.mark.parametrize("up,dn", [(13, 119), (3, 7), (5, 4), (16, 15), (17, 40), (3, 170)])
+def test_front_end_two_channels_in_one_launch(up, dn):
+    """prc_frontend_execute2 / HipBackend.front_end2 (main.py:133-149: both recordings are tuned with one frequency and
+    the same block phases): both channels of a block in one workgroup, one rotation factor per input sample for the two.
+    Bit-identical to two one-channel calls of the same kernel form -- every raw type, blocks shorter than a window
+    (both ends 'line'-extended inside one workgroup), an even decimation (padded LDS layout), pieces of a recording with
+    block0 -- and for the ratios the group form does not carry (up = 17, a 64 x 170 window) the fallback runs the two
+    channels one after the other."""
+    import torch
+    from passiveradar_amd import _lib
+    from passiveradar_amd.stream import HipBackend
+    rng = np.random.default_rng(up * 1000 + dn)
+    fs, foff = 2_400_000, 100_000
+    be = HipBackend(4096, 16, 32, 2.6e5, batch=4, clutter=None)
+    for dt, n_in, nblk in (("int8", 9001, 5), ("int16", 700, 2), ("float32", 32 * dn + 5, 1), ("uint8", 2 * dn + 3, 4)):
+        if dt == "float32":
+            ra, rb = (rng.standard_normal(2 * n_in * nblk).astype(np.float32) for _ in range(2))
+        else:
+            info = np.iinfo(dt)
+            ra, rb = (rng.integers(info.min, info.max, 2 * n_in * nblk, endpoint=True).astype(dt) for _ in range(2))
+        args = (2 * n_in, foff, fs, up, dn)
+        one_a, one_b = be.front_end(ra, *args, max_blocks=2), be.front_end(rb, *args, max_blocks=2)
+        two_a, two_b = be.front_end2(ra, rb, *args, max_blocks=2)
+        torch.cuda.synchronize()
+        assert torch.equal(two_a, one_a) and torch.equal(two_b, one_b), dt
+        assert rel_err(two_b.cpu().numpy(), O.front_end(rb, 2 * n_in, foff, fs, up, dn)) < TIGHT, dt
+        if nblk > 2:                       # a recording converted in pieces: the block phases continue (block0)
+            n_out = one_a.shape[0] // nblk
+            pa, pb = torch.zeros_like(one_a), torch.zeros_like(one_b)
+            for b0, m in ((0, 1), (1, nblk - 1)):
+                sl = slice(b0 * 2 * n_in, (b0 + m) * 2 * n_in)
+                be.front_end2(ra[sl], rb[sl], *args, max_blocks=2, block0=b0,
+                              out_ref=pa[b0 * n_out:(b0 + m) * n_out], out_srv=pb[b0 * n_out:(b0 + m) * n_out])
+            torch.cuda.synchronize()
+            assert torch.equal(pa, one_a) and torch.equal(pb, one_b), dt
+    with pytest.raises(ValueError):
+        be.front_end2(ra, rb[:-2], *args)
+    with pytest.raises(ValueError):
+        be.front_end(ra, *args, out=torch.zeros(3, dtype=torch.complex64, device="cuda"))      # ADVICE r4: too short
+    with pytest.raises(ValueError):
+        be.front_end(ra, *args, out=torch.zeros(1 << 20, dtype=torch.float32, device="cuda"))  # wrong dtype
+
+
+@pytest.mark.parametrize("H,W,fw,gw", [(1024, 177, 18, 4), (512, 257, 18, 4), (5, 7, 18, 4), (33, 64, 7, 2), (70, 90, 31, 11)])
+def test_cfar_of_the_complex_map_in_one_kernel(H, W, fw, gw):
+    """CFAR_2D_abs(X) = CFAR_2D(np.abs(X)) as range_doppler_plot.py:56-57 calls it, |X| taken on the tile load
+    (prc_cfar2d_c64): against the oracle on np.abs(X), against the two-step device path, both kernel forms, host arrays
+    and device tensors, ratio and threshold outputs"""
+    import torch
+    from passiveradar_amd import _lib
+    from passiveradar_amd.target_detection import CFAR_2D, CFAR_2D_abs
+    rng = np.random.default_rng(H * 1000 + W + 1)
+    X = (rng.standard_normal((3, H, W)) + 1j * rng.standard_normal((3, H, W))).astype(np.complex64)
+    X[1, H // 2, W // 3] += 1e3
+    old = _lib.get_option(_lib.OPT_CFAR_METHOD)
+    try:
+        for method in (0, 1):
+            _lib.set_option(_lib.OPT_CFAR_METHOD, method)
+            got = CFAR_2D_abs(torch.from_numpy(X).cuda(), fw, gw).cpu().numpy()
+            two = CFAR_2D(torch.from_numpy(np.abs(X)).cuda(), fw, gw).cpu().numpy()
+            assert rel_err(got, two) < 2e-6, method           # hypotf on the device against NumPy's: an ulp of the input
+            for k in range(3):
+                assert rel_err(got[k], O.CFAR_2D(np.abs(X[k]), fw, gw)) < TIGHT, (method, k)
+        one = CFAR_2D_abs(X[0], fw, gw)
+        assert one.dtype == np.float64 and one.shape == (H, W) and rel_err(one, O.CFAR_2D(np.abs(X[0]), fw, gw)) < TIGHT
+        thr = float(np.median(one))
+        det = CFAR_2D_abs(X[0], fw, gw, thr)
+        assert det.dtype == bool and (det != (one > thr)).mean() < 1e-3
+    finally:
+        _lib.set_option(_lib.OPT_CFAR_METHOD, old)
+    with pytest.raises(ValueError):
+        CFAR_2D_abs(X[0, 0], fw, gw)

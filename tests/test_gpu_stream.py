@@ -535,3 +535,31 @@ def test_front_end_in_pieces_continues_the_block_phases():
     torch.cuda.synchronize()
     assert torch.equal(out[5:5 + 7 * n_out], whole)
     assert float(out[:5].abs().max()) == 0.0 and float(out[-5:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("nframes,batch", [(7, 4), (8, 8), (3, 2)])
+def test_multi_illuminator_frames_in_two_lanes(nframes, batch):
+    """HipBackend(caf_lanes=2).frames_multi: alternate half-batches of frames on two plans / two streams (so that one
+    piece's Doppler launch runs under the next piece's segment launch, bench.py --workload cfg5) give the maps of the
+    one-plan path bit for bit, joined to the calling stream or not, call after call into the same buffers"""
+    import torch
+    from passiveradar_amd import scene
+    from passiveradar_amd.stream import HipBackend
+    C, R, F, fs, nref = 16384, 600, 256, 1.0e6, 3
+    refs, srv = scene.make_multi_scene((nframes + 1) * C, fs, 200, [11, 12, 13])
+    one = HipBackend(2 * C, R, F, fs, clutter=None, batch=batch, nref=nref)
+    two = HipBackend(2 * C, R, F, fs, clutter=None, batch=batch, nref=nref, caf_lanes=2)
+    assert two.caf_lanes == 2 and one.caf_lanes == 1
+    rp = [one.padded(r) for r in refs]
+    sp = one.padded(srv)
+    want = one.frames_multi(rp, sp, 0, nframes)
+    got = two.frames_multi(rp, sp, 0, nframes)
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        assert torch.equal(w, g)
+    outs = [torch.zeros_like(w) for w in want]
+    for _ in range(3):                                  # a resident pipeline: no join between the calls
+        two.frames_multi(rp, sp, 0, nframes, outs, join=False)
+    torch.cuda.synchronize()
+    for w, g in zip(want, outs):
+        assert torch.equal(w, g)
