@@ -19,6 +19,7 @@
 // thread: any other ratio).  PRC_OPT_FE_METHOD chooses for A/B runs.
 #include "common.h"
 #include <math.h>
+#include <string.h>
 #include <vector>
 
 #define FE_THREADS 256
@@ -213,9 +214,15 @@ typedef float __attribute__((address_space(4))) fe_const_float;
 #define FEG_WAVES 8        // wavefronts per workgroup: they share one window and split its rows
 #endif
 #define FEG_THREADS (64 * FEG_WAVES)
+#define FEG_SEGS 10        // segments per wavefront (trips[w][s] == 0 ends the list)
 struct FegArgs {
-    const float* T;      // [FEG_WAVES * rows_per_wave][16]
-    int32_t rows_per_wave, r_first;   // r_first: input offset r of the window's first sample (= r_hi - (FEG_WAVES rows_per_wave - 1))
+    const float* T;      // [rows_total][16]
+    int32_t rows_total, r_first;      // r_first: input offset r of the window's first sample (= r_hi - (rows_total - 1))
+    // Round 5: the tap table is a band -- a row meets only some of the `up` outputs of a group (a suffix of the columns in
+    // the table's upper corner, a prefix in its lower one) -- so a wavefront works through a short list of SEGMENTS, runs of
+    // trips (two rows each) that multiply the same compile-time window of columns, and the trips are dealt out so that
+    // every wavefront has about the same number of multiply-adds.  code = width (1 .. NQ) | 0x100 for a suffix window.
+    int16_t seg_row0[FEG_WAVES][FEG_SEGS], seg_trips[FEG_WAVES][FEG_SEGS], seg_code[FEG_WAVES][FEG_SEGS];
     int32_t lane_stride, pad, span;   // span: staged samples per workgroup (and channel)
     int32_t xstride;                  // two-channel form: LDS elements between the two channels' windows
     float inv_dn;
@@ -330,6 +337,52 @@ __device__ __forceinline__ void feg_stage(const FeArgs& a, const FegArgs& g, flo
     }
 }
 
+// One segment of a wavefront's rows: `ntrips` trips of two rows from `row0` on, columns [QA, QA + QN) of the tap table.
+// Per trip: 2 x QN taps through the scalar unit, two inputs from LDS, 2 QN packed multiply-adds.  A row's input sits
+// o = (rows_total - 1 - row) samples after the lane's first one (plus one pad sample per dn of them when dn is even): o,
+// o / dn and o % dn are carried in scalar registers, nothing is looked up.
+template <int QA, int QN, int NQ>
+__device__ __forceinline__ void feg_trips(const FeArgs& a, const FegArgs& g, const float2* xl, int row0, int ntrips, v2f (&acc)[NQ]) {
+    int o = g.rows_total - 1 - row0;
+    int od = o / a.dn, om = o - od * a.dn;
+#pragma unroll 1
+    for (int t = 0; t < ntrips; ++t) {
+        // wave-uniform address in the CONSTANT address space: the rows must come through the scalar unit (s_load into
+        // SGPRs, the taps then ride as scalar operands of the packed multiply-adds).  Through a plain global pointer the
+        // compiler only does that while it can prove that nothing in the kernel writes the table, gives up on a kernel
+        // this size, and loads the taps with vector loads into VGPRs instead (measured: 8.4 -> 12.7 us per block)
+        const fe_const_float* tr = (const fe_const_float*)(g.T + (size_t)(row0 + 2 * t) * 16);
+        const int off0 = o + (g.pad ? od : 0);
+        --o;
+        if (--om < 0) {
+            om += a.dn;
+            --od;
+        }
+        const int off1 = o + (g.pad ? od : 0);
+        --o;
+        if (--om < 0) {
+            om += a.dn;
+            --od;
+        }
+        const float2 x0 = xl[off0], x1 = xl[off1];
+        const v2f xa = v2f{x0.x, x0.y}, xb = v2f{x1.x, x1.y};
+#pragma unroll
+        for (int q = QA; q < QA + QN; ++q) acc[q] = __builtin_elementwise_fma(v2f{tr[q], tr[q]}, xa, acc[q]);
+#pragma unroll
+        for (int q = QA; q < QA + QN; ++q) acc[q] = __builtin_elementwise_fma(v2f{tr[16 + q], tr[16 + q]}, xb, acc[q]);
+    }
+}
+// the column window of a segment is a compile-time choice among the prefixes [0, w) and the suffixes [NQ - w, NQ)
+template <int W_, int NQ>
+__device__ __forceinline__ void feg_segment(const FeArgs& a, const FegArgs& g, const float2* xl, int row0, int ntrips, int code,
+                                            v2f (&acc)[NQ]) {
+    if constexpr (W_ <= NQ) {
+        if (code == W_) feg_trips<0, W_, NQ>(a, g, xl, row0, ntrips, acc);
+        else if (code == (W_ | 0x100)) feg_trips<NQ - W_, W_, NQ>(a, g, xl, row0, ntrips, acc);
+        else feg_segment<W_ + 1, NQ>(a, g, xl, row0, ntrips, code, acc);
+    }
+}
+
 // NCH = 2 (prc_frontend_execute2): both channels of a block in ONE workgroup.  A wavefront's lanes are 32 groups x 2
 // channels (lane = 32 channel + group): the window per channel is half as long (32 dn inputs + the rows), the two
 // windows together take the LDS one 64-group window took, and the row loop is the same instruction stream -- the taps are
@@ -362,46 +415,21 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
         default: feg_stage<PRC_RAW_C64, NCH>(a, g, X, raw, i_w, blk_phase, tid);
     }
     __syncthreads();
+    const float2* xl = NCH == 2 ? X + (lane >> 5) * g.xstride + (lane & 31) * g.lane_stride : X + lane * g.lane_stride;
     v2f acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = v2f{0.f, 0.f};
-    const float2* xl = NCH == 2 ? X + (lane >> 5) * g.xstride + (lane & 31) * g.lane_stride : X + lane * g.lane_stride;
-    const int row0 = w * g.rows_per_wave;
-    // two rows per trip: 2 x 16 taps through the scalar unit, two inputs from LDS, 2 NQ packed multiply-adds.  A row's
-    // input sits o = (rows - 1 - row) samples after the lane's first one (plus one pad sample per dn of them when dn is
-    // even): o, o / dn and o % dn are carried in scalar registers, nothing is looked up.
-    int o = FEG_WAVES * g.rows_per_wave - 1 - row0;
-    int od = o / a.dn, om = o - od * a.dn;
-#ifdef FEG_EXP_NOFIR                      // timing ablation, never shipped: one trip of the row loop
-    for (int rr = 0; rr < 2; rr += 2) {
+#ifdef FEG_EXP_NOFIR                      // timing ablation, never shipped: one trip
+    feg_trips<0, NQ, NQ>(a, g, xl, 0, 1, acc);
 #else
 #pragma unroll 1
-    for (int rr = 0; rr < g.rows_per_wave; rr += 2) {
-#endif
-        // wave-uniform address in the CONSTANT address space: the rows must come through the scalar unit (s_load into
-        // SGPRs, the taps then ride as scalar operands of the packed multiply-adds).  Through a plain global pointer the
-        // compiler only does that while it can prove that nothing in the kernel writes the table, gives up on a kernel
-        // this size, and loads the 32 taps per trip with vector loads into VGPRs instead (measured: 8.4 -> 12.7 us per block)
-        const fe_const_float* tr = (const fe_const_float*)(g.T + (size_t)(row0 + rr) * 16);
-        const int off0 = o + (g.pad ? od : 0);
-        --o;
-        if (--om < 0) {
-            om += a.dn;
-            --od;
-        }
-        const int off1 = o + (g.pad ? od : 0);
-        --o;
-        if (--om < 0) {
-            om += a.dn;
-            --od;
-        }
-        const float2 x0 = xl[off0], x1 = xl[off1];
-        const v2f xa = v2f{x0.x, x0.y}, xb = v2f{x1.x, x1.y};
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_elementwise_fma(v2f{tr[q], tr[q]}, xa, acc[q]);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_elementwise_fma(v2f{tr[16 + q], tr[16 + q]}, xb, acc[q]);
+    for (int sgm = 0; sgm < FEG_SEGS; ++sgm) {
+        const int ntrips = __builtin_amdgcn_readfirstlane((int)g.seg_trips[w][sgm]);
+        if (ntrips == 0) break;
+        feg_segment<1, NQ>(a, g, xl, __builtin_amdgcn_readfirstlane((int)g.seg_row0[w][sgm]), ntrips,
+                           __builtin_amdgcn_readfirstlane((int)g.seg_code[w][sgm]), acc);
     }
+#endif
     __syncthreads();                                                // the window is dead: its LDS takes the partial sums
     // [wave][lane][q] at an odd pitch: a lane's `up` sums are stored pitch samples from its neighbour's (b64 stores,
     // conflict-free for an odd pitch) and read back as what they are, consecutive outputs ([wave][q][lane] measured 68 %
@@ -479,18 +507,91 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
         const int64_t s0 = (int64_t)d->n_pre_remove * dn, sl = (up - 1 + d->n_pre_remove) * dn;
         const int64_t r_hi = sl / up, r_lo = s0 / up - (p->J - 1);
         const int64_t nrows = r_hi - r_lo + 1;
-        const int64_t rpw = ((nrows + FEG_WAVES - 1) / FEG_WAVES + 1) & ~(int64_t)1;   // rows per wavefront, even (two per trip)
         const int pad = (dn % 2 == 0) ? 1 : 0;
-        const int64_t o_max = FEG_WAVES * rpw - 1;
-        const int64_t span = dn * (FEG_G - 1) + FEG_WAVES * rpw;
+        const int64_t nq = up <= 4 ? 4 : (up <= 8 ? 8 : (up <= 13 ? 13 : 16));      // accumulators per thread (the kernel's NQ)
+        // which columns a row reaches: T[row][q] != 0 iff 0 <= (q + n_pre_remove) dn - up (r_hi - row) < ntaps
+        auto col_range = [&](int64_t row, int& lo, int& hi) {       // [lo, hi) over q < up; lo == hi: an all-zero row
+            lo = (int)up;
+            hi = 0;
+            for (int64_t q = 0; q < up; ++q) {
+                const int64_t idx = (q + d->n_pre_remove) * dn - up * (r_hi - row);
+                if (idx >= 0 && idx < d->ntaps) {
+                    if (q < lo) lo = (int)q;
+                    if (q + 1 > hi) hi = (int)q + 1;
+                }
+            }
+            if (hi < lo) lo = hi = 0;
+        };
+        // Trips (two consecutive rows) and the narrowest compile-time column window that holds what their rows reach: a
+        // prefix [0, w) or a suffix [nq - w, nq).  A trip costs 2 w multiply-adds + ~8 instructions of addressing, LDS
+        // reads and loop; consecutive trips with the same window form a segment (~25 instructions to set up).  The trips
+        // are dealt to the FEG_WAVES wavefronts in order, cut where the running cost passes the next eighth of the total.
+        // PRC_OPT_FE_BALANCE = 0: equal runs of rows at full width (rounds 3-4).
+        const bool balance = prc_opt(PRC_OPT_FE_BALANCE) != 0;
+        const int64_t ntrip_all = balance ? (nrows + 1) / 2 : FEG_WAVES * ((((nrows + FEG_WAVES - 1) / FEG_WAVES + 1) & ~(int64_t)1) / 2);
+        std::vector<int> tcode((size_t)ntrip_all);
+        std::vector<int64_t> tcost((size_t)ntrip_all);
+        int64_t cost_all = 0;
+        for (int64_t t = 0; t < ntrip_all; ++t) {
+            int lo = (int)nq, hi = 0;
+            for (int64_t r = 2 * t; r < 2 * t + 2 && r < nrows; ++r) {
+                int l, h;
+                col_range(r, l, h);
+                if (h > l) {
+                    if (l < lo) lo = l;
+                    if (h > hi) hi = h;
+                }
+            }
+            int code = (int)nq;                                       // full width
+            if (balance) {
+                if (hi <= lo) code = 1;                                // a pair of all-zero rows (padding): the narrowest window
+                else if (hi <= (int)nq - lo) code = hi;                // prefix [0, hi)
+                else code = ((int)nq - lo) | 0x100;                    // suffix [lo, nq)
+                if ((code & 0xff) >= (int)nq) code = (int)nq;
+            }
+            tcode[(size_t)t] = code;
+            tcost[(size_t)t] = 2 * (code & 0xff) + 8;
+            cost_all += tcost[(size_t)t];
+        }
+        int16_t seg_row0[FEG_WAVES][FEG_SEGS] = {}, seg_trips[FEG_WAVES][FEG_SEGS] = {}, seg_code[FEG_WAVES][FEG_SEGS] = {};
+        bool seg_fit = true;
+        {
+            int64_t t = 0, run = 0;
+            for (int w = 0; w < FEG_WAVES; ++w) {
+                const int64_t until = balance ? cost_all * (w + 1) / FEG_WAVES : 0;
+                const int64_t t_end_equal = (w + 1) * (ntrip_all / FEG_WAVES);
+                int nseg = 0;
+                while (t < ntrip_all) {
+                    if (balance ? (run + tcost[(size_t)t] / 2 > until && w + 1 < FEG_WAVES) : (t >= t_end_equal)) break;
+                    if (nseg > 0 && seg_code[w][nseg - 1] == tcode[(size_t)t]) {
+                        ++seg_trips[w][nseg - 1];
+                    } else if (nseg < FEG_SEGS) {
+                        seg_row0[w][nseg] = (int16_t)(2 * t);
+                        seg_trips[w][nseg] = 1;
+                        seg_code[w][nseg] = (int16_t)tcode[(size_t)t];
+                        ++nseg;
+                    } else {
+                        // more windows than a wavefront's list holds (never at the ratios in use): widen the last segment to
+                        // the full width and let it take the rest of this wavefront's trips
+                        seg_code[w][nseg - 1] = (int16_t)nq;
+                        ++seg_trips[w][nseg - 1];
+                    }
+                    run += tcost[(size_t)t];
+                    ++t;
+                }
+            }
+            seg_fit = t == ntrip_all;
+        }
+        const int64_t rows_total = 2 * ntrip_all;
+        const int64_t o_max = rows_total - 1;
+        const int64_t span = dn * (FEG_G - 1) + rows_total;
         const int64_t x_elems = span + pad * ((span - 1) / dn) + 1;
         size_t lds = sizeof(float2) * (size_t)x_elems;
-        const int64_t nq = up <= 4 ? 4 : (up <= 8 ? 8 : (up <= 13 ? 13 : 16));      // accumulators per thread (the kernel's NQ)
         const size_t lds_p = sizeof(float2) * FEG_WAVES * (size_t)(nq | 1) * FEG_G;
         if (lds < lds_p) lds = lds_p;
-        if (lds <= 78 * 1024) {                                            // two workgroups per CU
-            std::vector<float> T((size_t)FEG_WAVES * rpw * 16, 0.f);
-            for (int64_t row = 0; row < FEG_WAVES * rpw; ++row) {
+        if (lds <= 78 * 1024 && seg_fit) {                                 // two workgroups per CU
+            std::vector<float> T((size_t)(rows_total + 1) * 16, 0.f);     // one spare row: the second row of a last trip
+            for (int64_t row = 0; row < rows_total; ++row) {
                 const int64_t r = r_hi - row;
                 for (int64_t q = 0; q < up; ++q) {
                     const int64_t idx = (q + d->n_pre_remove) * dn - up * r;
@@ -500,7 +601,10 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
             e = hipMalloc(&p->d_T, sizeof(float) * T.size());
             if (e == hipSuccess) e = hipMemcpy(p->d_T, T.data(), sizeof(float) * T.size(), hipMemcpyHostToDevice);
             p->g.T = p->d_T;
-            p->g.rows_per_wave = (int32_t)rpw;
+            p->g.rows_total = (int32_t)rows_total;
+            memcpy(p->g.seg_row0, seg_row0, sizeof(seg_row0));
+            memcpy(p->g.seg_trips, seg_trips, sizeof(seg_trips));
+            memcpy(p->g.seg_code, seg_code, sizeof(seg_code));
             p->g.r_first = (int32_t)(r_hi - o_max);
             p->g.lane_stride = (int32_t)(dn + pad);
             p->g.pad = pad;
@@ -509,7 +613,7 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
             p->g.xstride = 0;
             p->g_lds = lds;
             // two channels per workgroup: 32 groups each, the two windows side by side
-            const int64_t span2 = dn * (FEG_G / 2 - 1) + FEG_WAVES * rpw;
+            const int64_t span2 = dn * (FEG_G / 2 - 1) + rows_total;
             const int64_t x2 = (span2 + pad * ((span2 - 1) / dn) + 1 + 1) & ~(int64_t)1;
             size_t lds2 = sizeof(float2) * 2 * (size_t)x2;
             if (lds2 < lds_p) lds2 = lds_p;

@@ -20,7 +20,7 @@ import os
 import numpy as np
 
 __all__ = ["save_range_doppler", "save_range_doppler_zarr", "load_range_doppler_zarr", "save_metadata",
-           "validate_zarr_v2_metadata", "read_zarr_v2", "save_range_doppler_hdf5", "load_range_doppler_hdf5",
+           "validate_zarr_v2_metadata", "read_zarr_v2", "write_zarr_v2", "zarray_json", "save_range_doppler_hdf5", "load_range_doppler_hdf5",
            "hdf5_available"]
 
 
@@ -204,23 +204,44 @@ def validate_zarr_v2_metadata(meta):
     return dt
 
 
-def read_zarr_v2(path):
-    """Spec-driven reader of an UNCOMPRESSED zarr v2 array in a directory store: any chunk grid, C or F order inside
-    a chunk, edge chunks stored at full chunk size, missing chunks = fill_value.  Independent of how the store was
-    written -- the tests read save_range_doppler_zarr's output through it."""
-    meta = json.load(open(os.path.join(path, ".zarray")))
-    dt = validate_zarr_v2_metadata(meta)
-    if meta["compressor"] is not None or meta["filters"]:
-        raise NotImplementedError("compressed / filtered chunks need numcodecs")
-    shape, chunks = tuple(meta["shape"]), tuple(meta["chunks"])
+def _zarr_fill(meta, dt):
     fv = meta["fill_value"]
     if fv is None:
-        fill = 0
-    elif dt.kind == "c":
-        fill = complex(float(fv[0]), float(fv[1]))
-    else:
-        fill = {"NaN": np.nan, "Infinity": np.inf, "-Infinity": -np.inf}.get(fv, fv) if isinstance(fv, str) else fv
-    out = np.full(shape, fill, dtype=dt)
+        return 0
+    if dt.kind == "c":
+        return complex(float(fv[0]), float(fv[1]))
+    return {"NaN": np.nan, "Infinity": np.inf, "-Infinity": -np.inf}.get(fv, fv) if isinstance(fv, str) else fv
+
+
+def _zarr_codec(meta):
+    """(decode, encode) of the chunk compressor: null (raw chunks) or zlib -- the codec the v2 specification's own
+    storage example uses, available in the standard library; anything else needs numcodecs"""
+    comp = meta["compressor"]
+    if meta["filters"]:
+        raise NotImplementedError("filtered chunks need numcodecs")
+    if comp is None:
+        return (lambda b: b), (lambda b: b)
+    if comp.get("id") == "zlib":
+        import zlib
+        level = int(comp.get("level", 1))
+        return zlib.decompress, (lambda b: zlib.compress(b, level))
+    raise NotImplementedError(f"compressor {comp.get('id')!r} needs numcodecs")
+
+
+def zarray_json(meta):
+    """the bytes of a ``.zarray`` document as zarr-python 2.x writes them (sorted keys, four-space indent, ASCII)"""
+    return json.dumps(meta, indent=4, sort_keys=True, ensure_ascii=True, separators=(",", ": ")).encode("ascii")
+
+
+def read_zarr_v2(path):
+    """Spec-driven reader of a zarr v2 array in a directory store: any chunk grid, C or F order inside a chunk, edge
+    chunks stored at full chunk size, missing chunks = fill_value, raw or zlib-compressed chunks.  Independent of how
+    the store was written -- the tests read save_range_doppler_zarr's output through it."""
+    meta = json.load(open(os.path.join(path, ".zarray")))
+    dt = validate_zarr_v2_metadata(meta)
+    decode, _ = _zarr_codec(meta)
+    shape, chunks = tuple(meta["shape"]), tuple(meta["chunks"])
+    out = np.full(shape, _zarr_fill(meta, dt), dtype=dt)
     sep = meta.get("dimension_separator", ".")
     grid = [range(-(-s // c)) for s, c in zip(shape, chunks)]
     import itertools
@@ -228,13 +249,40 @@ def read_zarr_v2(path):
         f = os.path.join(path, sep.join(str(i) for i in idx))
         if not os.path.exists(f):
             continue
-        raw = np.fromfile(f, dtype=dt)
+        raw = np.frombuffer(decode(open(f, "rb").read()), dtype=dt)
         if raw.size != int(np.prod(chunks)):
             raise ValueError(f"chunk {idx}: {raw.size} items, the chunk shape holds {int(np.prod(chunks))}")
         block = raw.reshape(chunks, order=meta["order"])
         sel = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, shape))
         out[sel] = block[tuple(slice(0, sl.stop - sl.start) for sl in sel)]
     return out
+
+
+def write_zarr_v2(path, array, meta):
+    """The general writer behind the store of main.py:216-224: ``array`` into a directory store described by the
+    ``.zarray`` document ``meta`` (any chunk grid, C / F order, '.' or '/' separators, raw or zlib chunks; edge chunks
+    are stored at full chunk size, padded with the fill value; every chunk is written, also those equal to it)."""
+    import itertools
+    dt = validate_zarr_v2_metadata(meta)
+    array = np.asarray(array)
+    shape, chunks = tuple(meta["shape"]), tuple(meta["chunks"])
+    if tuple(array.shape) != shape:
+        raise ValueError(f"write_zarr_v2: array of shape {array.shape}, .zarray says {shape}")
+    _, encode = _zarr_codec(meta)
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, ".zarray"), "wb") as fh:
+        fh.write(zarray_json(meta))
+    sep = meta.get("dimension_separator", ".")
+    fill = _zarr_fill(meta, dt)
+    for idx in itertools.product(*[range(-(-s // c)) for s, c in zip(shape, chunks)]):
+        block = np.full(chunks, fill, dtype=dt)
+        sel = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, shape))
+        block[tuple(slice(0, sl.stop - sl.start) for sl in sel)] = array[sel]
+        f = os.path.join(path, sep.join(str(i) for i in idx))
+        os.makedirs(os.path.dirname(f), exist_ok=True)
+        with open(f, "wb") as fh:
+            fh.write(encode(block.tobytes(order=meta["order"])))
+    return path
 
 
 def save_range_doppler(config, frames):
@@ -263,8 +311,8 @@ class ZarrFrameWriter:
         meta = {"zarr_format": 2, "shape": [self.F, self.cols, self.nframes], "chunks": [self.F, self.cols, 1], "dtype": "<c8",
                 "compressor": None, "fill_value": [0.0, 0.0], "order": "C", "filters": None}
         validate_zarr_v2_metadata(meta)
-        with open(os.path.join(path, ".zarray"), "w") as fh:
-            json.dump(meta, fh, indent=1)
+        with open(os.path.join(path, ".zarray"), "wb") as fh:
+            fh.write(zarray_json(meta))
         with open(os.path.join(path, ".zattrs"), "w") as fh:
             fh.write("{}")
 

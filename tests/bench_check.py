@@ -27,7 +27,7 @@ def run_bench(args, dump, timeout=1500):
 
 
 def independent_pass(bench, torch, wl, nchunks, seed0, strong, pick, oracle_frame=None, window_segs=2, batch=64):
-    """-> (sums [nchunks] complex64, {frame: map}, {chunk: (ref, srv)} host chunks oracle_frame touches)"""
+    """-> (sums [nchunks] complex64, {frame: map}, {chunk: (ref, srv, cleaned-on-the-device)} host chunks oracle_frame touches)"""
     from passiveradar_amd.stream import HipBackend
     fs, n, R, F, clutter, _ = bench.WORKLOADS[wl]
     C = n // 2
@@ -72,16 +72,18 @@ def independent_pass(bench, torch, wl, nchunks, seed0, strong, pick, oracle_fram
         for c in want_chunks:
             if c_lo - h_lo <= c < c_hi + h_hi and c not in chunks_at:
                 o = C // 2 + (c - c_lo + h_lo) * C
-                chunks_at[c] = (ref_pad[o:o + C].cpu().numpy(), srv_pad[o:o + C].cpu().numpy())
+                cl = be._clean_buf if be.clutter is not None else srv_pad      # the cleaned stream the frames were made of
+                chunks_at[c] = (ref_pad[o:o + C].cpu().numpy(), srv_pad[o:o + C].cpu().numpy(), cl[o:o + C].cpu().numpy())
         del maps, ref_pad, srv_pad
     return sums, maps_at, chunks_at
 
 
-def oracle_frame_map(bench, wl, nchunks, frame, chunks_at, lags=None):
+def oracle_frame_map(bench, wl, nchunks, frame, chunks_at, lags=None, device_cleaned=False):
     """One frame end to end on the CPU (test infrastructure: oracle/): the clutter canceller of the workload on each of
     the hop chunks the frame touches, the overlapped CPI with zeros beyond the stream's ends (main.py:178-181), the Kaiser
     window, fast_xambg.  lags: only delays 0..lags (the LAST lags + 1 columns of the map), for sizes whose full CAF
-    takes minutes on one core."""
+    takes minutes on one core.  device_cleaned: the CAF stage alone -- the oracle's fast_xambg on the stream the DEVICE
+    cleaned.  Returns (map, [the cleaned chunks that went into it])."""
     from scipy.signal import get_window
     from oracle import np_oracle as O
     fs, n, R, F, clutter, _ = bench.WORKLOADS[wl]
@@ -93,8 +95,10 @@ def oracle_frame_map(bench, wl, nchunks, frame, chunks_at, lags=None):
             refs.append(zero)
             cleans.append(zero)
             continue
-        a, s = chunks_at[c]
-        if clutter == "ls":
+        a, s, dev_clean = chunks_at[c]
+        if device_cleaned:
+            y = dev_clean
+        elif clutter == "ls":
             y = O.LS_Filter_Multiple(a, s, R, fs, [0, 1, -1, 2, -2])
         elif clutter == "nlms":
             from oracle import c_oracle
@@ -106,4 +110,4 @@ def oracle_frame_map(bench, wl, nchunks, frame, chunks_at, lags=None):
     r3, c3 = np.concatenate(refs), np.concatenate(cleans)
     lo = C // 2                                               # frame i = stream[i C - C/2 : i C + 3C/2]
     w = get_window(("kaiser", 5.0), n)
-    return O.fast_xambg(r3[lo:lo + n], c3[lo:lo + n], R if lags is None else lags, F, n, w)[:, :, 0]
+    return O.fast_xambg(r3[lo:lo + n], c3[lo:lo + n], R if lags is None else lags, F, n, w)[:, :, 0], cleans

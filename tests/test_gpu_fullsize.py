@@ -15,7 +15,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gpu_ready")]
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _check(tmp_path, wl, bench_args, nframes, strong, oracle_lags=None, window_segs=2, batch=64, ridge_tol=None):
+def _check(tmp_path, wl, bench_args, nframes, strong, oracle_lags=None, window_segs=2, batch=64, nlms=False):
     import torch
     sys.path.insert(0, REPO)
     import bench
@@ -39,24 +39,33 @@ def _check(tmp_path, wl, bench_args, nframes, strong, oracle_lags=None, window_s
     e_sum = rel_err(d["ill0_sums"], sums)
     assert e_sum < 1e-4, e_sum
     # the LAST frame (the highest byte offsets of the resident streams) end to end on the CPU
-    exp = bench_check.oracle_frame_map(bench, wl, nframes, last, chunks_at, lags=oracle_lags)
+    peak = float(np.abs(got[pick.index(last)]).max())
     mine = got[pick.index(last)]
     if oracle_lags is not None:
         mine = mine[:, -(oracle_lags + 1):]
-    d_or = np.abs(mine - exp) / np.abs(got[pick.index(last)]).max()
-    F = d_or.shape[0]
-    off_ridge = np.ones(F, bool)
-    off_ridge[F // 2 - 1:F // 2 + 2] = False
-    e_or, e_off = float(d_or.max()), float(d_or[off_ridge].max())
-    print(f"{wl}: {nframes} frames, picked maps vs independent pass {errs}, sums {e_sum:.2e}, last frame vs oracle {e_or:.2e} "
-          f"({e_off:.2e} off the zero-Doppler ridge); {line['value']:.0f} frames/s in the dumped run")
-    # LS: the device sums its correlations in double where it matters and the oracle is a float64 evaluation -- 1e-4 on
-    # every cell.  NLMS is a float32 recursion in the reference, in the C twin and on the device alike: two summation
-    # orders leave ~2e-5 of the stream as tap noise, which integrates coherently on the cancelled clutter ridge (the three
-    # rows around zero Doppler) of a map whose peak is a 1 % target -- the same statement, and the same two bounds, as
-    # test_cfg2_pipeline_against_reference_output makes for the reference's own float32 correlations.
-    assert e_off < 1e-4, (e_or, e_off)
-    assert e_or < (1e-4 if ridge_tol is None else ridge_tol), (e_or, e_off)
+    exp, cleans = bench_check.oracle_frame_map(bench, wl, nframes, last, chunks_at, lags=oracle_lags)
+    e_or = float(np.abs(mine - exp).max() / peak)
+    msg = (f"{wl}: {nframes} frames, picked maps vs independent pass {errs}, sums {e_sum:.2e}, last frame vs oracle end to end "
+           f"{e_or:.2e}; {line['value']:.0f} frames/s in the dumped run")
+    if not nlms:
+        # LS: the device sums its correlations in double where it matters and the oracle is a float64 evaluation
+        print(msg)
+        assert e_or < 1e-4, e_or
+        return
+    # NLMS is a float32 recursion in the reference, in the C twin and on the device alike.  Two summation orders leave
+    # ~2e-5 of the stream's level as differences in the taps' jitter; the jitter modulates the cancelled clutter, so the
+    # differences are coherent with the reference channel and spread over the adaptation bandwidth (mu fs / T, ~100 Doppler
+    # rows here) of a map whose peak is a 1 % target.  So the end-to-end number is reported and held to 5e-4, and the two
+    # stages are held to the bar separately: the cleaned stream against the C twin at the stream's own scale (as
+    # test_nlms_full_cfg3_hop_vs_c_oracle), the CAF of the DEVICE-cleaned stream against the oracle's fast_xambg.
+    exp_caf, _ = bench_check.oracle_frame_map(bench, wl, nframes, last, chunks_at, lags=oracle_lags, device_cleaned=True)
+    e_caf = float(np.abs(mine - exp_caf).max() / peak)
+    e_clean = 0.0
+    for k, c in enumerate((last - 1, last, last + 1)):
+        if 0 <= c < nframes:
+            e_clean = max(e_clean, float(np.abs(chunks_at[c][2] - cleans[k]).max() / np.abs(chunks_at[c][1]).max()))
+    print(msg + f"; CAF stage alone {e_caf:.2e}, cleaned stream vs the C twin {e_clean:.2e} of the stream's peak")
+    assert e_caf < 1e-4 and e_clean < 1e-4 and e_or < 5e-4, (e_or, e_caf, e_clean)
 
 
 def test_default_bench_step_at_its_real_size(tmp_path):
@@ -73,4 +82,4 @@ def test_config3_nlms_launch_at_its_real_size(tmp_path):
     """bench.py --workload cfg3: 3072 hop chunks of 2.5 M samples through ONE NLMS launch (three wavefronts per SIMD),
     then 3072 frames of 1024 x 1025; the oracle leg runs the C twin's NLMS over the two hops under the last frame and
     the CAF on delays 0..127 (the full 1025-lag CAF takes two minutes on one host core)"""
-    _check(tmp_path, "cfg3", ["--workload", "cfg3"], 3072, False, oracle_lags=127, window_segs=5, batch=32, ridge_tol=5e-4)
+    _check(tmp_path, "cfg3", ["--workload", "cfg3"], 3072, False, oracle_lags=127, window_segs=5, batch=32, nlms=True)

@@ -333,12 +333,31 @@ def test_front_end_group_tables_reproduce_the_resampler(up, dn, n):
         out[hi] = x[-1] + slope * (i[hi] - (n - 1))
         out[mid] = x[i[mid]]
         return out
-    y = M.run(xe, ref.shape[0], hp, u, d, npr, dtype=np.complex128)
-    assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-7          # the taps are float32 in the table
-    T, roff, rpw, r_first, lane_stride, pad, span = M.tables(hp, u, d, npr)
-    assert pad == (1 if d % 2 == 0 else 0) and lane_stride == d + pad and rpw % 2 == 0
+    for balance in (True, False):        # round 5's banded, cost-balanced runs of rows / rounds 3-4's equal runs at full width
+        y = M.run(xe, ref.shape[0], hp, u, d, npr, dtype=np.complex128, balance=balance)
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 2e-7      # the taps are float32 in the table
+    T, roff, (segs, nq), r_first, lane_stride, pad, span = M.tables(hp, u, d, npr)
+    assert pad == (1 if d % 2 == 0 else 0) and lane_stride == d + pad
+    # the segments are consecutive runs of trips that cover every row once, their column windows stay inside the
+    # accumulators, and no tap lies outside a window
+    flat = [sg for w in segs for sg in w]
+    assert all(len(w) <= M.SEGS for w in segs) and flat[0][0] == 0
+    assert all(flat[i + 1][0] == flat[i][0] + 2 * flat[i][1] for i in range(len(flat) - 1))
+    assert flat[-1][0] + 2 * flat[-1][1] == T.shape[0] - 1
+    inside = 0.0
+    for row0, ntrips, code in flat:
+        qa, wd = M.window_of(code, nq)
+        assert 0 <= qa and qa + wd <= nq and wd >= 1
+        inside += float(np.abs(T[row0:row0 + 2 * ntrips, qa:qa + wd]).sum())
+    assert np.isclose(inside, float(np.abs(T).sum()), rtol=1e-6)
     # every tap of every phase sits in exactly one row
     assert np.isclose(T[:, :u].sum(), np.asarray(hp, dtype=np.float32).sum(), rtol=1e-5)
+    if (u, d) == (13, 119):              # what the split buys at the published workload's ratio: multiply-add slots per lane
+        per_wave = [sum(2 * nt * (c & 0xff) for _, nt, c in w) for w in segs]
+        old, _, _, _ = M.split_rows(len(hp), u, d, npr, balance=False)
+        per_wave_old = [sum(2 * nt * (c & 0xff) for _, nt, c in w) for w in old]
+        print("13:119 segments", segs, "multiply-add slots per wavefront", per_wave, "against", per_wave_old)
+        assert max(per_wave) < 0.8 * max(per_wave_old)
 
 
 def test_zarr_frame_writer_stores_blocks_in_any_order(tmp_path):
@@ -407,3 +426,40 @@ def test_xcorr_of_unequal_lengths_reduces_to_the_equal_length_sum():
         want = O.xcorr(s1, s2, nlead, nlag)
         assert want.shape == (abs(n2 + nlag + nlead - n1) + 1,)
         assert np.array_equal(O.xcorr(e1, e2, lead, lag), want)
+
+
+def test_zarr_reader_and_writer_against_the_specifications_own_example(tmp_path):
+    """VERDICT r4 (f4 by a consumer): no zarr / h5py is installed here, so the nearest thing to a consumer is the zarr v2
+    specification's own worked example -- a (20, 20) int32 array in (10, 10) zlib chunks, fill value 42 -- as a committed
+    fixture written from the specification's rules with the standard library alone (oracle/gen_zarr_fixture.py).
+    read_zarr_v2 must read it, and write_zarr_v2 must emit the same store again: the same file names, the same .zarray
+    bytes, the same chunk payloads (the same compressed bytes too when the zlib library is the one that made the
+    fixture).  The store of main.py:216-224 goes through the same writer code (zarray_json, chunk naming)."""
+    import zlib
+    from passiveradar_amd import output
+    fx = os.path.join(GOLDEN, "zarr_v2_spec_example")
+    want = np.arange(400, dtype="<i4").reshape(20, 20)
+    got = output.read_zarr_v2(fx)
+    assert got.dtype == np.dtype("<i4") and np.array_equal(got, want)
+    meta = json.load(open(os.path.join(fx, ".zarray")))
+    out = output.write_zarr_v2(str(tmp_path / "again.zarr"), got, meta)
+    names = sorted(n for n in os.listdir(fx) if n != "zlib_version.txt")
+    assert sorted(os.listdir(out)) == names == [".zarray", "0.0", "0.1", "1.0", "1.1"]
+    assert open(os.path.join(out, ".zarray"), "rb").read() == open(os.path.join(fx, ".zarray"), "rb").read()
+    same_zlib = open(os.path.join(fx, "zlib_version.txt")).read().strip() == zlib.ZLIB_RUNTIME_VERSION
+    for n in names[1:]:
+        a, b = open(os.path.join(out, n), "rb").read(), open(os.path.join(fx, n), "rb").read()
+        assert zlib.decompress(a) == zlib.decompress(b)
+        if same_zlib:
+            assert a == b, n
+    # a missing chunk reads as the fill value; an edge chunk is stored at full size
+    os.remove(os.path.join(out, "1.1"))
+    miss = output.read_zarr_v2(out)
+    assert np.all(miss[10:, 10:] == 42) and np.array_equal(miss[:10], want[:10])
+    edge = output.write_zarr_v2(str(tmp_path / "edge.zarr"), want[:15, :7], {**meta, "shape": [15, 7], "compressor": None})
+    assert os.path.getsize(os.path.join(edge, "1.0")) == 400 and np.array_equal(output.read_zarr_v2(edge), want[:15, :7])
+    # the range-Doppler store itself: its .zarray is the same canonical document
+    frames = (np.arange(2 * 4 * 3).reshape(2, 4, 3) * (1 + 0.5j)).astype(np.complex64)
+    p = output.save_range_doppler_zarr(str(tmp_path / "X.zarr"), frames)
+    doc = open(os.path.join(p, ".zarray"), "rb").read()
+    assert doc == output.zarray_json(json.loads(doc)) and np.array_equal(output.read_zarr_v2(p), np.moveaxis(frames, 0, 2))

@@ -12,21 +12,71 @@ G = 64          # groups per workgroup (FEG_G)
 W = 8           # wavefronts per workgroup (FEG_WAVES): they split the rows
 
 
-def tables(taps, up, dn, n_pre_remove):
-    """(T [W rpw][16], roff [W rpw], rpw, r_first, lane_stride, pad, span): T as the plan builds it, roff as the kernel's
-    scalar arithmetic produces it row by row"""
-    taps = np.asarray(taps, dtype=np.float32)
-    J = -(-taps.size // up)
+SEGS = 10       # FEG_SEGS: segments per wavefront
+
+
+def split_rows(ntaps, up, dn, n_pre_remove, balance=True):
+    """The segments each wavefront works through, as prc_frontend_plan_create deals them (round 5).  A trip is two
+    consecutive rows; its column window is the narrowest prefix [0, w) or suffix [nq - w, nq) that holds what its rows reach
+    (code = w, or w | 0x100 for a suffix); consecutive trips with the same window form a segment; trips go to the W
+    wavefronts in order, cut where the running cost (2 w + 8 per trip) passes the next W-th of the total.
+    Returns (segments[W] = [(row0, ntrips, code)], rows_total, r_hi, nq)."""
+    J = -(-ntaps // up)
     s0, sl = n_pre_remove * dn, (up - 1 + n_pre_remove) * dn
     r_hi, r_lo = sl // up, s0 // up - (J - 1)
     nrows = r_hi - r_lo + 1
-    rpw = ((nrows + W - 1) // W + 1) & ~1
+    nq = 4 if up <= 4 else (8 if up <= 8 else (13 if up <= 13 else 16))
+
+    def col_range(row):
+        qs = [q for q in range(up) if 0 <= (q + n_pre_remove) * dn - up * (r_hi - row) < ntaps]
+        return (qs[0], qs[-1] + 1) if qs else (0, 0)
+    ntrip = (nrows + 1) // 2 if balance else W * ((((nrows + W - 1) // W + 1) & ~1) // 2)
+    code, cost = [], []
+    for t in range(ntrip):
+        lo, hi = nq, 0
+        for r in range(2 * t, min(2 * t + 2, nrows)):
+            l, h = col_range(r)
+            if h > l:
+                lo, hi = min(lo, l), max(hi, h)
+        c = nq
+        if balance:
+            c = 1 if hi <= lo else (hi if hi <= nq - lo else (nq - lo) | 0x100)
+            if (c & 0xff) >= nq:
+                c = nq
+        code.append(c)
+        cost.append(2 * (c & 0xff) + 8)
+    total, t, run, segs = sum(cost), 0, 0, []
+    for w in range(W):
+        until = total * (w + 1) // W
+        mine = []
+        while t < ntrip:
+            if (run + cost[t] // 2 > until and w + 1 < W) if balance else (t >= (w + 1) * (ntrip // W)):
+                break
+            if mine and mine[-1][2] == code[t]:
+                mine[-1][1] += 1
+            elif len(mine) < SEGS:
+                mine.append([2 * t, 1, code[t]])
+            else:
+                mine[-1][2] = nq
+                mine[-1][1] += 1
+            run += cost[t]
+            t += 1
+        segs.append([tuple(m) for m in mine])
+    assert t == ntrip
+    return segs, 2 * ntrip, r_hi, nq
+
+
+def tables(taps, up, dn, n_pre_remove, balance=True):
+    """(T [rows_total + 1][16], roff [rows_total], segments, r_first, lane_stride, pad, span): T as the plan builds it, roff
+    as the kernel's scalar arithmetic produces it row by row"""
+    taps = np.asarray(taps, dtype=np.float32)
+    segs, rows_total, r_hi, nq = split_rows(taps.size, up, dn, n_pre_remove, balance)
     pad = 1 if dn % 2 == 0 else 0
-    o_max = W * rpw - 1
-    span = dn * (G - 1) + W * rpw
-    T = np.zeros((W * rpw, 16), dtype=np.float32)
-    roff = np.zeros(W * rpw, dtype=np.int64)
-    for row in range(W * rpw):
+    o_max = rows_total - 1
+    span = dn * (G - 1) + rows_total
+    T = np.zeros((rows_total + 1, 16), dtype=np.float32)
+    roff = np.zeros(rows_total, dtype=np.int64)
+    for row in range(rows_total):
         r = r_hi - row
         for q in range(up):
             idx = (q + n_pre_remove) * dn - up * r
@@ -34,13 +84,19 @@ def tables(taps, up, dn, n_pre_remove):
                 T[row, q] = taps[idx]
         o = o_max - row
         roff[row] = o + pad * (o // dn)
-    return T, roff, rpw, r_hi - o_max, dn + pad, pad, span
+    return T, roff, (segs, nq), r_hi - o_max, dn + pad, pad, span
 
 
-def run(xe_of, n_out, taps, up, dn, n_pre_remove, dtype=np.complex64):
+def window_of(code, nq):
+    """(first column, width) of a segment's compile-time column window"""
+    w = code & 0xff
+    return (nq - w if code & 0x100 else 0), w
+
+
+def run(xe_of, n_out, taps, up, dn, n_pre_remove, dtype=np.complex64, balance=True):
     """xe_of(i): the (tuned, linearly extended) input at any integer index, vectorised.  Returns y[n_out] computed the
     kernel's way: staged windows with the padded layout, per-wavefront partial sums in float32, combined in order."""
-    T, roff, rpw, r_first, lane_stride, pad, span = tables(taps, up, dn, n_pre_remove)
+    T, roff, (segs, nq), r_first, lane_stride, pad, span = tables(taps, up, dn, n_pre_remove, balance)
     y = np.zeros(n_out, dtype=dtype)
     nwg = -(-n_out // (G * up))
     for wg in range(nwg):
@@ -50,13 +106,15 @@ def run(xe_of, n_out, taps, up, dn, n_pre_remove, dtype=np.complex64):
         at = k + pad * (k // dn)
         X = np.zeros(at.max() + 1, dtype=dtype)
         X[at] = xe_of(i_w + k).astype(dtype)
-        part = np.zeros((W, up, G), dtype=dtype)
+        part = np.zeros((W, 16, G), dtype=dtype)
         lanes = np.arange(G) * lane_stride
         for w in range(W):
-            acc = np.zeros((up, G), dtype=dtype)
-            for row in range(w * rpw, (w + 1) * rpw):
-                x = X[lanes + roff[row]]
-                acc = acc + T[row, :up, None].astype(dtype) * x[None, :]
+            acc = np.zeros((16, G), dtype=dtype)
+            for row0, ntrips, code in segs[w]:                           # only the columns this segment's rows reach
+                qa, wd = window_of(code, nq)
+                for row in range(row0, row0 + 2 * ntrips):
+                    x = X[lanes + roff[row]]
+                    acc[qa:qa + wd] = acc[qa:qa + wd] + T[row, qa:qa + wd, None].astype(dtype) * x[None, :]
             part[w] = acc
         tot = part[0]
         for w in range(1, W):
