@@ -90,9 +90,10 @@ typedef enum prc_option {
                                      itself -- rocprofv3 --marker-trace shows the library's calls around its kernels.  The roctx
                                      library (librocprofiler-sdk-roctx.so.1, else libroctx64.so.4) is bound at run time, the first
                                      time the option is set; PRC_EUNSUPPORTED if neither loads.  Default 0: nothing is loaded    */
-    PRC_OPT_FE_BALANCE = 12,      /* front-end plans, read at creation: 1 (default) = the group kernel's wavefronts take runs of tap
-                                     rows of about equal cost and multiply only the output columns their rows reach; 0 = equal
-                                     runs at full width (A/B runs)                                                          */
+    PRC_OPT_FE_BALANCE = 12,      /* front-end plans, read at creation: 0 (default) = the group kernel's wavefronts take equal runs of
+                                     tap rows at full width; N > 0 = runs of about equal cost (2 w + N per two rows), each run
+                                     multiplying only the w output columns its rows reach (37 % fewer multiply-adds at 13:119;
+                                     measured no faster at any N, 7 % slower at N = 8: A/B runs)                             */
     PRC_OPT_COUNT_ = 13
 } prc_option;
 int prc_set_option(int32_t option, int64_t value);     /* PRC_EINVAL for an unknown option or a value out of range */

@@ -345,25 +345,27 @@ template <int QA, int QN, int NQ>
 __device__ __forceinline__ void feg_trips(const FeArgs& a, const FegArgs& g, const float2* xl, int row0, int ntrips, v2f (&acc)[NQ]) {
     int o = g.rows_total - 1 - row0;
     int od = o / a.dn, om = o - od * a.dn;
+    auto next_off = [&]() {                                      // LDS offset of the next row's input; rows only go down
+        const int off = o + (g.pad ? od : 0);
+        --o;
+        if (--om < 0) {
+            om += a.dn;
+            --od;
+        }
+        return off < 0 ? 0 : off;                                // (the look-ahead of a wavefront's last trip)
+    };
+    // wave-uniform address in the CONSTANT address space: the rows must come through the scalar unit (s_load into
+    // SGPRs, the taps then ride as scalar operands of the packed multiply-adds).  Through a plain global pointer the
+    // compiler only does that while it can prove that nothing in the kernel writes the table, gives up on a kernel
+    // this size, and loads the taps with vector loads into VGPRs instead (measured: 8.4 -> 12.7 us per block)
+    const fe_const_float* tr = (const fe_const_float*)(g.T + (size_t)row0 * 16);
+    // Measured in round 5 (profiles/r05_frontend_ab.md): requesting a row's taps and input one row ahead of their use (two
+    // register sets in turn, one explicit lgkmcnt(0) per row) changes nothing (8.7 -> 9.0 us per block-channel), and neither
+    // does dealing the rows out by cost with narrower column windows in the table's corners (PRC_OPT_FE_BALANCE: 37 % fewer
+    // multiply-adds, 8.6-9.4 us): this loop is not what bounds the kernel.
 #pragma unroll 1
-    for (int t = 0; t < ntrips; ++t) {
-        // wave-uniform address in the CONSTANT address space: the rows must come through the scalar unit (s_load into
-        // SGPRs, the taps then ride as scalar operands of the packed multiply-adds).  Through a plain global pointer the
-        // compiler only does that while it can prove that nothing in the kernel writes the table, gives up on a kernel
-        // this size, and loads the taps with vector loads into VGPRs instead (measured: 8.4 -> 12.7 us per block)
-        const fe_const_float* tr = (const fe_const_float*)(g.T + (size_t)(row0 + 2 * t) * 16);
-        const int off0 = o + (g.pad ? od : 0);
-        --o;
-        if (--om < 0) {
-            om += a.dn;
-            --od;
-        }
-        const int off1 = o + (g.pad ? od : 0);
-        --o;
-        if (--om < 0) {
-            om += a.dn;
-            --od;
-        }
+    for (int t = 0; t < ntrips; ++t, tr += 32) {
+        const int off0 = next_off(), off1 = next_off();
         const float2 x0 = xl[off0], x1 = xl[off1];
         const v2f xa = v2f{x0.x, x0.y}, xb = v2f{x1.x, x1.y};
 #pragma unroll
@@ -527,7 +529,8 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
         // reads and loop; consecutive trips with the same window form a segment (~25 instructions to set up).  The trips
         // are dealt to the FEG_WAVES wavefronts in order, cut where the running cost passes the next eighth of the total.
         // PRC_OPT_FE_BALANCE = 0: equal runs of rows at full width (rounds 3-4).
-        const bool balance = prc_opt(PRC_OPT_FE_BALANCE) != 0;
+        const int64_t trip_overhead = prc_opt(PRC_OPT_FE_BALANCE);          // 0: equal runs; else the cost model's constant per trip
+        const bool balance = trip_overhead != 0;
         const int64_t ntrip_all = balance ? (nrows + 1) / 2 : FEG_WAVES * ((((nrows + FEG_WAVES - 1) / FEG_WAVES + 1) & ~(int64_t)1) / 2);
         std::vector<int> tcode((size_t)ntrip_all);
         std::vector<int64_t> tcost((size_t)ntrip_all);
@@ -550,7 +553,7 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
                 if ((code & 0xff) >= (int)nq) code = (int)nq;
             }
             tcode[(size_t)t] = code;
-            tcost[(size_t)t] = 2 * (code & 0xff) + 8;
+            tcost[(size_t)t] = 2 * (code & 0xff) + trip_overhead;
             cost_all += tcost[(size_t)t];
         }
         int16_t seg_row0[FEG_WAVES][FEG_SEGS] = {}, seg_trips[FEG_WAVES][FEG_SEGS] = {}, seg_code[FEG_WAVES][FEG_SEGS] = {};
@@ -590,7 +593,7 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
         const size_t lds_p = sizeof(float2) * FEG_WAVES * (size_t)(nq | 1) * FEG_G;
         if (lds < lds_p) lds = lds_p;
         if (lds <= 78 * 1024 && seg_fit) {                                 // two workgroups per CU
-            std::vector<float> T((size_t)(rows_total + 1) * 16, 0.f);     // one spare row: the second row of a last trip
+            std::vector<float> T((size_t)(rows_total + 3) * 16, 0.f);     // spare rows: the look-ahead of a wavefront's last trip
             for (int64_t row = 0; row < rows_total; ++row) {
                 const int64_t r = r_hi - row;
                 for (int64_t q = 0; q < up; ++q) {
