@@ -584,9 +584,10 @@ def main():
                     help="cfg4, N>1: gather a shard's maps in this many rounds, each as soon as its frames are done "
                          "(1 = one gather after the whole shard)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--caf-lanes", type=int, default=2,
-                    help="cfg5: 2 (default) = alternate half-batches of frames on two plans / streams, so one piece's Doppler "
-                         "launch runs under the next piece's segment launch; 1 = one plan, stage after stage")
+    ap.add_argument("--caf-lanes", type=int, default=1,
+                    help="cfg5: 1 (default) = one plan, stage after stage; 2 = alternate half-batches of frames on two plans / "
+                         "streams, so one piece's Doppler launch may run under the next piece's segment launch (measured in "
+                         "round 5: 3690 against 3703 frames/s -- no idle share to recover)")
     ap.add_argument("--no-multi", action="store_true",
                     help="cfg5: one fast_xambg pass per illuminator instead of the shared-surveillance multi call")
     ap.add_argument("--cpu-workers", default="32",

@@ -145,9 +145,14 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
         const int hi_f = hi - tail;                            // last sample that goes through the transforms
 
         for (int lb = 0; lb < a.nlagblk; ++lb) {
+#ifdef CAFT_EXP_NOACC           // timing ablation, never shipped (wrong results): the accumulator shares the registers of the
+            float2 v[16];       // surveillance spectrum -- what the kernel would run like if its state were 64 VGPRs, not 96
+            float2(&acc)[16] = v;
+#else
             float2 acc[16];
 #pragma unroll
             for (int m = 0; m < 16; ++m) acc[m] = make_float2(0.f, 0.f);
+#endif
 
             // Software pipeline as in caf_fft.hip: raw buffer loads issued one transform ahead of their use; the
             // descriptor's num_records encodes "samples of this piece that exist" (zero padding of U, ragged
@@ -230,7 +235,11 @@ __global__ __launch_bounds__(FT_THREADS, CAFT_WAVES_PER_SIMD) void caf_fft_team_
             for (int n0 = lo; n0 <= hi_f; n0 += B) {
                 const int rem = hi_f - n0 + 1;
                 const int cnt = rem < B ? rem : B;
+#ifdef CAFT_EXP_NOACC
+                float2 u[16];
+#else
                 float2 u[16], v[16];
+#endif
                 // zero-padded reference piece: a piece of at most 2048 (3072) samples leaves registers 8..15 (12..15) of
                 // every thread zero -- their loads, window products and first-pass additions are skipped (uniform branch)
                 const int nz = cnt <= 2048 ? 8 : (cnt <= 3072 ? 12 : 16);

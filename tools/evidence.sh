@@ -65,6 +65,10 @@ trace trace_cfg2 --no-cpu --frames 1024 --steps 5 --warmup 1
 trace trace_cfg2_serial --no-cpu --frames 1024 --steps 5 --warmup 1 --no-overlap
 trace trace_cfg3 --no-cpu --workload cfg3 --frames 512 --steps 1 --warmup 1
 trace trace_cfg5 --no-cpu --workload cfg5 --steps 20 --warmup 2
+trace trace_cfg5_lanes2 --no-cpu --workload cfg5 --steps 20 --warmup 2 --caf-lanes 2
+# the library's entry points as roctx ranges around the kernels they enqueue (PRC_OPT_MARKERS)
+echo "rocprofv3 --marker-trace --kernel-trace --stats -- python bench.py --markers --no-cpu --frames 512 --steps 2 --warmup 1" > $E/markers_cfg2.cmd.txt
+rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $E/markers_cfg2 -o t -- $B --markers --no-cpu --frames 512 --steps 2 --warmup 1 > $E/markers_cfg2.log 2>&1
 # 3. counters
 pmc pmc_cfg2 --no-cpu --frames 256 --steps 2 --warmup 1 --no-overlap
 pmc pmc_cfg3 --no-cpu --workload cfg3 --no-clutter --frames 64 --steps 2 --warmup 1

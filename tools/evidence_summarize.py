@@ -41,7 +41,34 @@ for name in ("bench_default", "bench_default_allcores", "bench_cfg3", "bench_cfg
         json.dump(d, open(os.path.join(S, f"{tag}_{name}.json"), "w"), indent=1)
 
 # ---- kernel traces -------------------------------------------------------------------------------------------------
-for name in ("trace_cfg2", "trace_cfg2_serial", "trace_cfg3", "trace_cfg5"):
+def timeline(name):
+    """what the kernel trace says about the timed steps' timeline: the span of the library's kernels, the time at least one
+    of them was running (union), the sum of their durations (sum - union = time two ran together), the idle share"""
+    fs = glob.glob(os.path.join(E, name, "**", "*kernel_trace.csv"), recursive=True)
+    if not fs:
+        return ""
+    rows = [r for r in csv.DictReader(open(fs[0])) if short(r["Kernel_Name"]).startswith(OURS)]
+    if len(rows) < 8:
+        return ""
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows)
+    iv = iv[len(iv) // 4:]                                      # the last three quarters: warm-up and per-kernel timing launches aside
+    span = max(e for _, e in iv) - iv[0][0]
+    total = sum(e - s_ for s_, e in iv)
+    union, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+    for s_, e in iv[1:]:
+        if s_ > cur_e:
+            union += cur_e - cur_s
+            cur_s, cur_e = s_, e
+        else:
+            cur_e = max(cur_e, e)
+    union += cur_e - cur_s
+    return (f"\nTimeline of the library's kernels (last three quarters of the launches, from the kernel trace's timestamps): span "
+            f"{span / 1e6:.3f} ms, at least one kernel running {union / 1e6:.3f} ms ({100 * union / span:.1f} %), idle "
+            f"{100 * (span - union) / span:.1f} %, sum of kernel durations {total / 1e6:.3f} ms -- two kernels ran together for "
+            f"{(total - union) / 1e6:.3f} ms ({100 * (total - union) / span:.1f} % of the span).\n")
+
+
+for name in ("trace_cfg2", "trace_cfg2_serial", "trace_cfg3", "trace_cfg5", "trace_cfg5_lanes2"):
     fs = glob.glob(os.path.join(E, name, "**", "*kernel_stats.csv"), recursive=True)
     line = load_line(name)
     if not fs or not line:
@@ -62,6 +89,7 @@ for name in ("trace_cfg2", "trace_cfg2_serial", "trace_cfg3", "trace_cfg5"):
                 "| bench name | avg ms / launch | launches / step | algorithmic GB/s or TFLOP/s |\n|---|---|---|---|\n")
         for k, v in line["kernels"].items():
             f.write(f"| {k} | {v['avg_ms_per_launch']:.4f} | {v['launches_per_step']} | {v.get('algorithmic_GBps', v.get('algorithmic_TFLOPs', 0)):.1f} |\n")
+        f.write(timeline(name))
         f.write("\nbench.py line of this run:\n\n```\n" + json.dumps(line) + "\n```\n")
 
 # ---- counters --------------------------------------------------------------------------------------------------------
