@@ -185,6 +185,61 @@ def cpu_baseline(workload, max_workers=32, asis=False):
     }
 
 
+KERNEL_FAMILY = {"caf_segments": ("caf_fft_kernel", "caf_fft_team_kernel", "caf_fft_team_multi_kernel", "caf_direct_kernel"),
+                 "caf_doppler": ("doppler_col_kernel", "shift_transpose_kernel", "transpose_jk_kj_kernel"),
+                 "ls_correlate": ("ls_corr_cached_kernel", "ls_corr_cached_team_kernel"),
+                 "ls_fir_subtract": ("ls_fused_cached_kernel", "ls_fused_cached_team_kernel")}
+
+
+def measure_traffic(wl, family, frames, extra_args=(), timeout=240):
+    """roofline.traffic MEASURED by this run (it used to be a constant from a file): two child runs of this
+    script under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters only, no trace domain, as
+    MI355X_MICROARCH.md prescribes -- on ``frames`` frames of the same workload (one launch of the dominant kernel covers
+    as many units as in the timed run), stages back to back on one stream.  Returns (bytes per launch of the kernel family
+    = 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of the guide for wide coalesced reads, averaged over the launches
+    with the largest grid; a note) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    names = KERNEL_FAMILY.get(family)
+    if not names:
+        return None, f"no counter family for {family}"
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="prc_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+                   os.path.join(REPO, "bench.py"), "--workload", wl, "--frames", str(frames), "--steps", "1", "--warmup", "1",
+                   "--no-cpu", "--no-overlap", "--traffic", "none"] + list(extra_args)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} child failed (rc {r.returncode})"
+            vals = []
+            for fcsv in files:
+                for row in csv.DictReader(open(fcsv)):
+                    k = row["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]
+                    if row["Counter_Name"] == ctr and k in names:
+                        vals.append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+            if not vals:
+                return None, f"no {family} launch in the --pmc {ctr} pass"
+            big = max(g for g, _ in vals)
+            sel = [v for g, v in vals if g == big]
+            got[ctr] = sum(sel) / len(sel) * 1e3                     # rocprofv3 reports KB
+        except Exception as e:                                       # noqa: BLE001 -- a measurement aid must never take the line down
+            return None, f"--pmc {ctr} pass: {e!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], (
+        f"measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of bench.py --workload {wl} "
+        f"--frames {frames} --no-overlap, 2 x FETCH_SIZE + WRITE_SIZE per launch (FETCH {got['FETCH_SIZE'] / 1e6:.1f} MB x 2, "
+        f"WRITE {got['WRITE_SIZE'] / 1e6:.1f} MB)")
+
+
 def fm_suppression(L=64):
     """SURVEY 8d's report-only figure: clutter suppression (dB) of the five-bin LS chain on an FM-like illuminator
     (badly conditioned Toeplitz system), device vs the oracle's per-bin complex128 Levinson (CPU, test infrastructure)."""
@@ -599,6 +654,10 @@ def main():
     ap.add_argument("--shard-of", default=None, metavar="RANK/WORLD",
                     help="cfg4 on ONE GPU: process only the shard rank RANK of WORLD would own (its frames + the two halo "
                          "chunks), no gather -- what one rank of an N-GPU run computes, measurable on a 1-GPU box")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "file", "none"],
+                    help="roofline.traffic: measure = two rocprofv3 --pmc child passes of this script (FETCH_SIZE, WRITE_SIZE) on "
+                         "one launch's worth of frames; file = the per-unit figures of profiles/traffic_latest.json (an earlier "
+                         "run); auto = measure on one GPU when the CPU leg runs too (the default line), else file; none")
     ap.add_argument("--markers", action="store_true",
                     help="PRC_OPT_MARKERS: the library's entry points open roctx ranges (rocprofv3 --marker-trace)")
     ap.add_argument("--dump", default=None, metavar="NPZ",
@@ -984,20 +1043,34 @@ def main():
         else:
             achieved = d["work"] / (d["ms"] * 1e-3) / 1e9
             traffic, tsrc = None, None
+            units = min(nlocal, be.sub) if dom.startswith("ls_") else nb     # hop chunks (frames) behind one launch of `dom`
+            mode = args.traffic
+            if mode == "auto":
+                mode = "measure" if (world == 1 and not args.no_cpu and nill == 1) else "file"
+            if mode == "measure":
+                extra = ["--sub-batch", str(args.sub_batch)] + (["--no-clutter"] if args.no_clutter else [])
+                traffic, tsrc = measure_traffic(wl, dom, units, extra)
+                if traffic is None:
+                    tsrc = f"not measured ({tsrc}); "
+                    mode = "file"
             tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
-            if os.path.exists(tpath):
+            if mode == "file" and os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     traffic = tj.get("cfg2" if wl == "cfg4" else wl, {}).get(dom)
                     if traffic is not None:
                         # the file holds bytes per chunk / frame; an LS launch covers one LS sub-batch, a CAF launch nb frames
-                        traffic = traffic * (min(nlocal, be.sub) if dom.startswith("ls_") else nb)
-                        tsrc = tj.get("_source", "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier "
-                                                 "run of this command; not measured by this run)")
+                        traffic = traffic * units
+                        tsrc = (tsrc or "") + tj.get("_source", "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
+                                                                "earlier run of this command; not measured by this run)")
                 except Exception:
                     traffic = None
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc}
+            if traffic:
+                # the figure to improve: the kernel's rate on the bytes the counters saw
+                roof["achieved_measured_traffic"] = traffic / (d["ms"] * 1e-3) / 1e9
+                roof["frac_measured_traffic"] = roof["achieved_measured_traffic"] / HBM_PEAK_GBS
             if "compulsory_work" in d:
                 # the same launch priced on the bytes the fused form cannot avoid (real traffic, PMC: the same to 2 %)
                 roof["achieved_compulsory_bytes"] = d["compulsory_work"] / (d["ms"] * 1e-3) / 1e9

@@ -729,7 +729,9 @@ class StreamProcessor:
         the LS + CAF pipeline.  ``config`` is the dict of passiveradar_amd.config.getConfiguration."""
         args = (config["input_chunk_length"], config["offset_freq"], config["input_sample_rate"],
                 config["resamp_up"], config["resamp_dn"])
-        if hasattr(self.backend, "front_end2") and np.shape(raw_ref) == np.shape(raw_srv):
+        shape = lambda x: tuple(x.shape) if hasattr(x, "shape") else (len(x),)      # host arrays, lists or device tensors
+        same_type = str(getattr(raw_ref, "dtype", "")) == str(getattr(raw_srv, "dtype", ""))
+        if hasattr(self.backend, "front_end2") and shape(raw_ref) == shape(raw_srv) and same_type:
             ref, srv = self.backend.front_end2(raw_ref, raw_srv, *args)       # one launch per batch of blocks for both
         else:
             ref = self.backend.front_end(raw_ref, *args)
