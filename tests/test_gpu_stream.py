@@ -563,3 +563,26 @@ def test_multi_illuminator_frames_in_two_lanes(nframes, batch):
     torch.cuda.synchronize()
     for w, g in zip(want, outs):
         assert torch.equal(w, g)
+
+
+def test_bench_measures_its_own_traffic(tmp_path):
+    """roofline.traffic used to be a constant from a file.  bench.py --traffic measure runs itself twice under
+    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: separate passes, counters only) on one launch's worth of frames and
+    reports 2 x FETCH + WRITE of the dominant kernel -- the line says so, and the figure is the fused LS pass's 28-30 MB per
+    chunk-bin (the default line takes this path whenever its CPU leg runs: `--traffic auto`)."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 is not on PATH")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--no-cpu", "--steps", "2", "--warmup", "1", "--frames", "300",
+                        "--traffic", "measure"], capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    roof = d["roofline"]
+    assert roof["kernel"] == "ls_fir_subtract" and roof["traffic_source"].startswith("measured by this run"), roof
+    per_chunk_bin = roof["traffic"] / 256.0            # an LS launch of the 300-frame step covers 256 hop chunks
+    assert 26e6 < per_chunk_bin < 32e6, per_chunk_bin
+    assert 0.3 < roof["frac_measured_traffic"] < roof["frac"] < 1.2
