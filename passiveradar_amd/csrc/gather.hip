@@ -14,27 +14,33 @@
 #include <dlfcn.h>
 #include <string.h>
 #include <vector>
+// Types, enum values and prototypes come from RCCL's own header (round 5; rounds 1-4 restated them by hand): the
+// function pointers below are declared as decltype(&ncclXxx), so a change of any signature, of ncclFloat32 or of the id's
+// size in the installed RCCL is a compile error here, not a silent mismatch at the first multi-GPU run.  Nothing is
+// linked: the header only declares, the symbols are still looked up in the library the process already carries.
+#include <rccl/rccl.h>
 
 namespace {
 
-typedef struct prc_nccl_comm* nccl_comm_t;
-struct nccl_unique_id { char internal[PRC_COMM_ID_BYTES]; };
-typedef int nccl_result_t;                    // ncclSuccess == 0
-constexpr int NCCL_FLOAT32 = 7;               // ncclFloat32 of rccl.h
+typedef ncclComm_t nccl_comm_t;
+typedef ncclUniqueId nccl_unique_id;
+typedef ncclResult_t nccl_result_t;
+constexpr ncclDataType_t NCCL_FLOAT32 = ncclFloat32;
+static_assert(sizeof(ncclUniqueId) == PRC_COMM_ID_BYTES, "prcore.h's PRC_COMM_ID_BYTES is RCCL's ncclUniqueId");
 
 struct RcclApi {
     void* handle = nullptr;
-    nccl_result_t (*GetUniqueId)(nccl_unique_id*) = nullptr;
-    nccl_result_t (*CommInitRank)(nccl_comm_t*, int, nccl_unique_id, int) = nullptr;
-    nccl_result_t (*CommDestroy)(nccl_comm_t) = nullptr;
-    nccl_result_t (*GroupStart)() = nullptr;
-    nccl_result_t (*GroupEnd)() = nullptr;
-    nccl_result_t (*Send)(const void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
-    nccl_result_t (*Recv)(void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(nccl_result_t) = nullptr;
-    nccl_result_t (*GetVersion)(int*) = nullptr;
-    nccl_result_t (*CommCount)(nccl_comm_t, int*) = nullptr;
-    nccl_result_t (*CommUserRank)(nccl_comm_t, int*) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
 };
 
 RcclApi g_rccl;
@@ -74,7 +80,7 @@ int rccl_load() {
 #define PRC_RCCL(call)                                                                   \
     do {                                                                                 \
         nccl_result_t r__ = (call);                                                      \
-        if (r__ != 0) {                                                                  \
+        if (r__ != ncclSuccess) {                                                                  \
             prc_set_error("%s failed: %s", #call, g_rccl.GetErrorString(r__));           \
             return PRC_EHIP;                                                             \
         }                                                                                \
@@ -155,7 +161,7 @@ extern "C" int prc_comm_loopback(prc_comm* c, const void* send, void* recv, int6
     // a send to oneself only completes against a receive posted in the same group
     PRC_RCCL(g_rccl.GroupStart());
     nccl_result_t a = g_rccl.Send(send, (size_t)nfloats, NCCL_FLOAT32, c->rank, c->comm, stream);
-    nccl_result_t b = a == 0 ? g_rccl.Recv(recv, (size_t)nfloats, NCCL_FLOAT32, c->rank, c->comm, stream) : 0;
+    nccl_result_t b = a == 0 ? g_rccl.Recv(recv, (size_t)nfloats, NCCL_FLOAT32, c->rank, c->comm, stream) : ncclSuccess;
     nccl_result_t end = g_rccl.GroupEnd();
     if (a != 0 || b != 0 || end != 0) {
         prc_set_error("prc_comm_loopback: RCCL send/receive to self failed: %s", g_rccl.GetErrorString(a ? a : (b ? b : end)));
@@ -213,7 +219,7 @@ extern "C" int prc_gather_frames(prc_comm* c, const void* send, const int64_t* f
     if (c->world == 1) return PRC_OK;
     PRC_RCCL(g_rccl.GroupStart());
     int64_t off = 0;
-    nccl_result_t bad = 0;
+    nccl_result_t bad = ncclSuccess;
     for (int r = 0; r < c->world; ++r) {
         const int64_t cnt = frames_per_rank_host[r];
         if (r != root && cnt > 0 && bad == 0)
