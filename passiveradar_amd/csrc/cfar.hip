@@ -84,7 +84,9 @@ __global__ __launch_bounds__(CF_TX * CF_TY) void cfar_kernel(const TIn* __restri
 // one (a strong cell under test never meets the noise it is compared with in one sum).  Tile 16 x 64 outputs per
 // workgroup; the wrap-around indices are advanced, not divided.
 #define CS_TX 64
+#ifndef CS_TY
 #define CS_TY 16
+#endif
 template <typename TIn>
 __global__ __launch_bounds__(256) void cfar_sep_kernel(const TIn* __restrict__ X, int H, int W, int fw, int e1, int e2,
                                                        float inv_cells, const float* __restrict__ partial, int npartial,
