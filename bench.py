@@ -191,7 +191,7 @@ KERNEL_FAMILY = {"caf_segments": ("caf_fft_kernel", "caf_fft_team_kernel", "caf_
                  "ls_fir_subtract": ("ls_fused_cached_kernel", "ls_fused_cached_team_kernel")}
 
 
-def measure_traffic(wl, family, frames, extra_args=(), timeout=240):
+def measure_traffic(wl, family, frames, extra_args=(), timeout=150):
     """roofline.traffic MEASURED by this run (it used to be a constant from a file): two child runs of this
     script under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters only, no trace domain, as
     MI355X_MICROARCH.md prescribes -- on ``frames`` frames of the same workload (one launch of the dominant kernel covers
