@@ -140,14 +140,16 @@ def _share_hip_runtime_with_torch():
     """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 under
     torch/lib (same SONAMEs as /opt/rocm's).  Whichever copy is loaded first serves every later user of that
     SONAME: if libprcore pulled in /opt/rocm's first, a later ``import torch`` would run on a runtime it was not
-    built with and report "No HIP GPUs are available".  So when torch is installed but not imported yet, its copy
-    is loaded first (without importing torch) -- the configuration every GPU test runs in."""
+    built with and report "No HIP GPUs are available".  So when torch is installed its copy is loaded first (without
+    importing torch) -- the configuration every GPU test runs in.  Found by the fuzz run with two caller threads: one thread
+    loading this library while another is half way through `import torch` used to take the "torch is already there" shortcut."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
-        return
+    # (no shortcut for "torch is in sys.modules": another thread may be in the middle of `import torch` -- the module is
+    # registered before its libraries are loaded -- and loading an already loaded library again is a no-op)
     try:
-        spec = importlib.util.find_spec("torch")
+        mod = sys.modules.get("torch")
+        spec = getattr(mod, "__spec__", None) if mod is not None else importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
     if spec is None or not spec.submodule_search_locations:

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FeArgs a) {
 // Inputs are staged tuned, as above.  dn even: a lane stride of dn complex samples would hit dn/gcd banks only; the
 // window is stored with one pad sample per dn.
 typedef float __attribute__((address_space(4))) fe_const_float;
+typedef v2f __attribute__((address_space(4))) fe_const_v2f;     // two adjacent taps of a row: one aligned SGPR pair
 #define FEG_G 64
 #ifndef FEG_WAVES
 #define FEG_WAVES 8        // wavefronts per workgroup: they share one window and split its rows
@@ -298,7 +299,13 @@ __device__ __forceinline__ void feg_stage_interior(const FeArgs& a, const FegArg
 #pragma unroll
         for (int c = 0; c < FEG_CHUNK; ++c) {
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) v[ch][c] = fe_load<SRC>(raw[ch], i_w + k0 + c * FEG_THREADS);
+            for (int ch = 0; ch < NCH; ++ch) {
+#ifdef FEG_EXP_NOLOAD                 // timing ablation, never shipped: the staging without its global loads
+                v[ch][c] = make_float2((float)(k0 + c), (float)ch);
+#else
+                v[ch][c] = fe_load<SRC>(raw[ch], i_w + k0 + c * FEG_THREADS);
+#endif
+            }
         }
         // the loads first, then everything that does not need them (the phases: most of the work) while they are in flight --
         // left alone the scheduler sinks the loads below the phase arithmetic
@@ -341,37 +348,76 @@ __device__ __forceinline__ void feg_stage(const FeArgs& a, const FegArgs& g, flo
 // Per trip: 2 x QN taps through the scalar unit, two inputs from LDS, 2 QN packed multiply-adds.  A row's input sits
 // o = (rows_total - 1 - row) samples after the lane's first one (plus one pad sample per dn of them when dn is even): o,
 // o / dn and o % dn are carried in scalar registers, nothing is looked up.
-template <int QA, int QN, int NQ>
+template <int QA, int QN, int NQ, bool PAD>
 __device__ __forceinline__ void feg_trips(const FeArgs& a, const FegArgs& g, const float2* xl, int row0, int ntrips, v2f (&acc)[NQ]) {
     int o = g.rows_total - 1 - row0;
-    int od = o / a.dn, om = o - od * a.dn;
+    int od = PAD ? o / a.dn : 0, om = PAD ? o - od * a.dn : 0;
     auto next_off = [&]() {                                      // LDS offset of the next row's input; rows only go down
-        const int off = o + (g.pad ? od : 0);
+        const int off = o + (PAD ? od : 0);
         --o;
-        if (--om < 0) {
+        if (PAD && --om < 0) {                                   // dn even: one pad sample per dn of them (carried, not divided)
             om += a.dn;
             --od;
         }
-        return off < 0 ? 0 : off;                                // (the look-ahead of a wavefront's last trip)
+        return off;
     };
     // wave-uniform address in the CONSTANT address space: the rows must come through the scalar unit (s_load into
     // SGPRs, the taps then ride as scalar operands of the packed multiply-adds).  Through a plain global pointer the
     // compiler only does that while it can prove that nothing in the kernel writes the table, gives up on a kernel
     // this size, and loads the taps with vector loads into VGPRs instead (measured: 8.4 -> 12.7 us per block)
     const fe_const_float* tr = (const fe_const_float*)(g.T + (size_t)row0 * 16);
-    // Measured in round 5 (profiles/r05_frontend_ab.md): requesting a row's taps and input one row ahead of their use (two
-    // register sets in turn, one explicit lgkmcnt(0) per row) changes nothing (8.7 -> 9.0 us per block-channel), and neither
-    // does dealing the rows out by cost with narrower column windows in the table's corners (PRC_OPT_FE_BALANCE: 37 % fewer
-    // multiply-adds, 8.6-9.4 us): this loop is not what bounds the kernel.
-#pragma unroll 1
-    for (int t = 0; t < ntrips; ++t, tr += 32) {
-        const int off0 = next_off(), off1 = next_off();
-        const float2 x0 = xl[off0], x1 = xl[off1];
+    // Measured in round 5 (profiles/r05_frontend_ab.md): requesting a trip's taps and inputs one trip ahead of their use
+    // (two register sets in turn, explicit lgkmcnt(0) waits) changes nothing, before and after the scalar work below was
+    // removed, and neither does dealing the rows out by cost with narrower column windows in the table's corners
+    // (PRC_OPT_FE_BALANCE: 37 % fewer multiply-adds).
+#ifdef FEG_EXP_SAMEROW                    // timing ablation, never shipped: every trip reads the same two tap rows (128 bytes of table)
+#define FEG_TR_STEP 0
+#else
+#define FEG_TR_STEP 32
+#endif
+    // Taps as SGPR PAIRS (round 5).  A packed multiply-add takes a 64-bit scalar source and op_sel / op_sel_hi say which
+    // half feeds each half of the result: the tap in the LOW half of a pair serves with op_sel_hi:[0,..], the one in the HIGH
+    // half with op_sel:[1,..] op_sel_hi:[1,..] -- two adjacent taps of a row are one aligned pair as s_load delivers them.
+    // Written as `fma(v2f{t, t}, x, acc)` the compiler wants every tap in the low half of a pair of its own and moves 26
+    // scalars per trip into place: 161 M scalar instructions per launch against 184 M vector ones (SQ_INSTS_SALU /
+    // SQ_INSTS_VALU), and the ONE scalar unit of a CU serves all sixteen wavefronts -- the row loop was bound by it, which
+    // is why neither fewer multiply-adds nor earlier requests moved it (profiles/r05_frontend_ab.md).
+    constexpr int Q0 = QA & ~1, Q1 = (QA + QN + 1) & ~1;         // whole pairs covering [QA, QA + QN); the extra columns are zeros
+    static_assert(Q1 <= 16, "a tap row has 16 slots");
+    constexpr int NP = (Q1 - Q0) / 2;                            // tap pairs per row
+    auto use = [&](const v2f (&pa)[NP], const v2f (&pb)[NP], float2 x0, float2 x1) {
         const v2f xa = v2f{x0.x, x0.y}, xb = v2f{x1.x, x1.y};
 #pragma unroll
-        for (int q = QA; q < QA + QN; ++q) acc[q] = __builtin_elementwise_fma(v2f{tr[q], tr[q]}, xa, acc[q]);
+        for (int j = 0; j < NP; ++j) {
+            const int q = Q0 + 2 * j;
+            if (q < NQ) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[q < NQ ? q : 0]) : "s"(pa[j]), "v"(xa));
+            if (q + 1 < NQ) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[q + 1 < NQ ? q + 1 : 0]) : "s"(pa[j]), "v"(xa));
+        }
 #pragma unroll
-        for (int q = QA; q < QA + QN; ++q) acc[q] = __builtin_elementwise_fma(v2f{tr[16 + q], tr[16 + q]}, xb, acc[q]);
+        for (int j = 0; j < NP; ++j) {
+            const int q = Q0 + 2 * j;
+            if (q < NQ) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[q < NQ ? q : 0]) : "s"(pb[j]), "v"(xb));
+            if (q + 1 < NQ) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[q + 1 < NQ ? q + 1 : 0]) : "s"(pb[j]), "v"(xb));
+        }
+    };
+    auto request = [&](v2f (&pa)[NP], v2f (&pb)[NP], float2& x0, float2& x1) {
+        const fe_const_v2f* tp = (const fe_const_v2f*)tr;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            pa[j] = tp[(Q0 >> 1) + j];
+            pb[j] = tp[8 + (Q0 >> 1) + j];
+        }
+        tr += FEG_TR_STEP;
+        const int off0 = next_off(), off1 = next_off();
+        x0 = xl[off0];
+        x1 = xl[off1];
+    };
+#pragma unroll 1
+    for (int t = 0; t < ntrips; ++t) {
+        v2f pa[NP], pb[NP];
+        float2 x0, x1;
+        request(pa, pb, x0, x1);
+        use(pa, pb, x0, x1);
     }
 }
 // the column window of a segment is a compile-time choice among the prefixes [0, w) and the suffixes [NQ - w, NQ)
@@ -379,8 +425,13 @@ template <int W_, int NQ>
 __device__ __forceinline__ void feg_segment(const FeArgs& a, const FegArgs& g, const float2* xl, int row0, int ntrips, int code,
                                             v2f (&acc)[NQ]) {
     if constexpr (W_ <= NQ) {
-        if (code == W_) feg_trips<0, W_, NQ>(a, g, xl, row0, ntrips, acc);
-        else if (code == (W_ | 0x100)) feg_trips<NQ - W_, W_, NQ>(a, g, xl, row0, ntrips, acc);
+        if (code == W_) {
+            if (g.pad) feg_trips<0, W_, NQ, true>(a, g, xl, row0, ntrips, acc);
+            else feg_trips<0, W_, NQ, false>(a, g, xl, row0, ntrips, acc);
+        } else if (code == (W_ | 0x100)) {
+            if (g.pad) feg_trips<NQ - W_, W_, NQ, true>(a, g, xl, row0, ntrips, acc);
+            else feg_trips<NQ - W_, W_, NQ, false>(a, g, xl, row0, ntrips, acc);
+        }
         else feg_segment<W_ + 1, NQ>(a, g, xl, row0, ntrips, code, acc);
     }
 }
@@ -422,7 +473,7 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = v2f{0.f, 0.f};
 #ifdef FEG_EXP_NOFIR                      // timing ablation, never shipped: one trip
-    feg_trips<0, NQ, NQ>(a, g, xl, 0, 1, acc);
+    feg_trips<0, NQ, NQ, false>(a, g, xl, 0, 1, acc);
 #else
 #pragma unroll 1
     for (int sgm = 0; sgm < FEG_SEGS; ++sgm) {

@@ -462,6 +462,36 @@ def test_library_first_then_torch_in_a_fresh_process():
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_library_and_torch_loaded_by_two_threads_at_once():
+    """found by the round-5 fuzz run with two caller threads: one thread loads libprcore while another is half way through
+    `import torch` (the module is in sys.modules before its libraries are loaded) -- the library then took /opt/rocm's HIP
+    runtime first and torch reported "No HIP GPUs are available".  Fresh interpreters, both orders of the race."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, threading, time, numpy as np\n"
+        "sys.path.insert(0, '.')\n"
+        "delay = float(sys.argv[1])\n"
+        "out = {}\n"
+        "def use_torch():\n"
+        "    import torch\n"
+        "    out['torch'] = float(torch.ones(4, device='cuda').sum().item())\n"
+        "def use_lib():\n"
+        "    time.sleep(delay)\n"
+        "    from passiveradar_amd import scene\n"
+        "    from passiveradar_amd.range_doppler_processing import fast_xambg\n"
+        "    ref, srv = scene.make_scene(8192, 1e4, 20, 1)\n"
+        "    out['lib'] = fast_xambg(ref, srv, 20, 32).shape\n"
+        "ts = [threading.Thread(target=use_torch), threading.Thread(target=use_lib)]\n"
+        "[t.start() for t in ts]; [t.join() for t in ts]\n"
+        "assert out.get('torch') == 4.0 and out.get('lib') == (32, 21, 1), out\n"
+        "print('ok')\n")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for delay in ("0.0", "0.05", "0.3", "1.0"):
+        r = subprocess.run([sys.executable, "-c", code, delay], cwd=repo, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, (delay, r.stderr[-2000:])
+
+
 @pytest.mark.parametrize("nstreams,L", [(5, 24), (9, 90), (1030, 24), (2100, 24), (3100, 24)])
 def test_nlms_many_streams(nstreams, L):
     """batched NLMS through the C ABI: independent streams at a stride, one wavefront each, 4 / 8 / 12 wavefronts
