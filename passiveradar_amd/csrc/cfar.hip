@@ -87,10 +87,18 @@ __global__ __launch_bounds__(CF_TX * CF_TY) void cfar_kernel(const TIn* __restri
 #ifndef CS_TY
 #define CS_TY 16
 #endif
-template <typename TIn>
-__global__ __launch_bounds__(256) void cfar_sep_kernel(const TIn* __restrict__ X, int H, int W, int fw, int e1, int e2,
+// FW > 0: the box and guard widths are compile-time constants (the instantiation for the reference's own call,
+// CFAR_2D(18, 4) at range_doppler_plot.py:57): the 2 fw-term sums unroll into straight-line LDS reads at immediate
+// offsets.  With run-time bounds every term costs a scalar add, compare and branch next to its LDS read and add -- the SQ
+// counters had SQ_INSTS_SALU at 0.74 of SQ_INSTS_VALU for this kernel, and a CU has ONE scalar unit for all its wavefronts
+// (profiles/r05_salu.md).  FW = 0: run-time widths (any other call).
+template <typename TIn, int FW, int GW>
+__global__ __launch_bounds__(256) void cfar_sep_kernel(const TIn* __restrict__ X, int H, int W, int fw_rt, int e1_rt, int e2_rt,
                                                        float inv_cells, const float* __restrict__ partial, int npartial,
                                                        float thresh, int use_thresh, float* __restrict__ out) {
+    constexpr int E1C = FW > 0 ? ((FW - GW) / 2 < 0 ? 0 : (FW - GW) / 2) : 0;
+    constexpr int E2C = FW > 0 ? (FW - E1C + 1 > FW ? FW : FW - E1C + 1) : 0;
+    const int fw = FW > 0 ? FW : fw_rt, e1 = FW > 0 ? E1C : e1_rt, e2 = FW > 0 ? E2C : e2_rt;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int th = CS_TY + fw - 1, tw = CS_TX + fw - 1, twp = tw | 1;
     float* tile = reinterpret_cast<float*>(smem_raw);        // th x twp
@@ -124,9 +132,18 @@ __global__ __launch_bounds__(256) void cfar_sep_kernel(const TIn* __restrict__ X
     for (int r = tq; r < th; r += 4) {
         const float* row = tile + r * twp + (fw - 1) + tx;   // tap b reads row[-b]
         float so = 0.f, sm = 0.f;
-        for (int b = 0; b < e1; ++b) so += row[-b];
-        for (int b = e1; b < e2; ++b) sm += row[-b];
-        for (int b = e2; b < fw; ++b) so += row[-b];
+        if (FW > 0) {
+#pragma unroll
+            for (int b = 0; b < E1C; ++b) so += row[-b];
+#pragma unroll
+            for (int b = E1C; b < E2C; ++b) sm += row[-b];
+#pragma unroll
+            for (int b = E2C; b < FW; ++b) so += row[-b];
+        } else {
+            for (int b = 0; b < e1; ++b) so += row[-b];
+            for (int b = e1; b < e2; ++b) sm += row[-b];
+            for (int b = e2; b < fw; ++b) so += row[-b];
+        }
         Ho[r * CS_TX + tx] = so;
         Hf[r * CS_TX + tx] = so + sm;
     }
@@ -138,9 +155,18 @@ __global__ __launch_bounds__(256) void cfar_sep_kernel(const TIn* __restrict__ X
         if (i >= H) break;
         float acc = 0.f;
         const int base = ((fw - 1) + ty) * CS_TX + tx;       // tap a reads [base - a CS_TX]
-        for (int a = 0; a < e1; ++a) acc += Hf[base - a * CS_TX];
-        for (int a = e1; a < e2; ++a) acc += Ho[base - a * CS_TX];
-        for (int a = e2; a < fw; ++a) acc += Hf[base - a * CS_TX];
+        if (FW > 0) {
+#pragma unroll
+            for (int a = 0; a < E1C; ++a) acc += Hf[base - a * CS_TX];
+#pragma unroll
+            for (int a = E1C; a < E2C; ++a) acc += Ho[base - a * CS_TX];
+#pragma unroll
+            for (int a = E2C; a < FW; ++a) acc += Hf[base - a * CS_TX];
+        } else {
+            for (int a = 0; a < e1; ++a) acc += Hf[base - a * CS_TX];
+            for (int a = e1; a < e2; ++a) acc += Ho[base - a * CS_TX];
+            for (int a = e2; a < fw; ++a) acc += Hf[base - a * CS_TX];
+        }
         const float xv = tile[((fw - 1) + ty - c) * twp + (fw - 1) + tx - c];
         const float cr = (xv / mean_abs) / (acc * inv_cells + 1e-10f);
         out[(int64_t)f * H * W + (int64_t)i * W + j] = use_thresh ? (cr > thresh ? 1.f : 0.f) : cr;
@@ -209,8 +235,12 @@ static int cfar_run(const TIn* X, int32_t H, int32_t W, int32_t fw, int32_t gw, 
     const size_t lds_sep = sizeof(float) * (th * twp + 2 * th * CS_TX);
     if (lds_sep <= 64 * 1024 && prc_opt(PRC_OPT_CFAR_METHOD) != 1) {
         dim3 grid((W + CS_TX - 1) / CS_TX, (H + CS_TY - 1) / CS_TY, nframes);
-        hipLaunchKernelGGL(cfar_sep_kernel<TIn>, grid, dim3(256), lds_sep, stream, X, H, W, fw, e1, e2, inv_cells, d_partial, np,
-                           thresh, use_thresh, out);
+        if (fw == 18 && gw == 4)
+            hipLaunchKernelGGL((cfar_sep_kernel<TIn, 18, 4>), grid, dim3(256), lds_sep, stream, X, H, W, fw, e1, e2, inv_cells,
+                               d_partial, np, thresh, use_thresh, out);
+        else
+            hipLaunchKernelGGL((cfar_sep_kernel<TIn, 0, 0>), grid, dim3(256), lds_sep, stream, X, H, W, fw, e1, e2, inv_cells,
+                               d_partial, np, thresh, use_thresh, out);
     } else {
         const size_t lds = sizeof(float) * (size_t)(CF_TY + fw - 1) * (CF_TX + fw - 1);
         PRC_REQUIRE(lds <= 64 * 1024, PRC_EUNSUPPORTED, "prc_cfar2d: kernel width %d too large", fw);
