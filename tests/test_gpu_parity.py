@@ -1182,3 +1182,35 @@ def test_cfar_of_the_complex_map_in_one_kernel(H, W, fw, gw):
         _lib.set_option(_lib.OPT_CFAR_METHOD, old)
     with pytest.raises(ValueError):
         CFAR_2D_abs(X[0, 0], fw, gw)
+
+
+@pytest.mark.parametrize("up,dn", [(13, 119), (3, 7), (5, 4), (16, 15), (2, 9)])
+def test_front_end_banded_row_split_gives_the_same_samples(up, dn):
+    """PRC_OPT_FE_BALANCE > 0 (an A/B option, read when a front-end plan is made): the group kernel's wavefronts take runs of
+    tap rows of about equal cost and multiply only the output columns their rows reach -- prefix / suffix windows rounded out
+    to whole SGPR pairs.  Same samples as the equal split to float32 rounding (the sums are split differently), the same
+    as the oracle, one and two channels."""
+    import torch
+    from passiveradar_amd import _lib
+    from passiveradar_amd.stream import HipBackend
+    rng = np.random.default_rng(up * 77 + dn)
+    n_in, nblk = 64 * dn + 37, 3
+    ra, rb = (rng.integers(-128, 127, 2 * n_in * nblk, endpoint=True).astype(np.int8) for _ in range(2))
+    args = (2 * n_in, 100_000, 2_400_000, up, dn)
+    exp = O.front_end(rb, *args)
+    old = _lib.get_option(_lib.OPT_FE_BALANCE)
+    got = {}
+    try:
+        for bal in (0, 8, 34, 200):
+            _lib.set_option(_lib.OPT_FE_BALANCE, bal)
+            be = HipBackend(4096, 16, 32, 2.6e5, batch=4, clutter=None)          # a fresh plan: the option is read at creation
+            one = be.front_end(rb, *args, max_blocks=2)
+            two = be.front_end2(ra, rb, *args, max_blocks=2)[1]
+            torch.cuda.synchronize()
+            assert torch.equal(one, two), bal
+            got[bal] = one.cpu().numpy()
+            assert rel_err(got[bal], exp) < TIGHT, bal
+    finally:
+        _lib.set_option(_lib.OPT_FE_BALANCE, old)
+    for bal in (8, 34, 200):
+        assert rel_err(got[bal], got[0]) < 2e-6, bal
