@@ -369,7 +369,7 @@ __device__ __forceinline__ void feg_trips(const FeArgs& a, const FegArgs& g, con
     // Measured in round 5 (profiles/r05_frontend_ab.md): requesting a trip's taps and inputs one trip ahead of their use
     // (two register sets in turn, explicit lgkmcnt(0) waits) changes nothing, before and after the scalar work below was
     // removed, and neither does dealing the rows out by cost with narrower column windows in the table's corners
-    // (PRC_OPT_FE_BALANCE: 37 % fewer multiply-adds).
+    // (PRC_OPT_FE_BALANCE: 37 % fewer multiply-adds), nor does a loop of four rows per iteration.
 #ifdef FEG_EXP_SAMEROW                    // timing ablation, never shipped: every trip reads the same two tap rows (128 bytes of table)
 #define FEG_TR_STEP 0
 #else
