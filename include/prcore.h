@@ -192,12 +192,11 @@ typedef struct prc_ls_desc {
                               <= 769 taps, n >= 8192: fewer cache bytes per sample; else as 3).  The FFT
                               kernels take up to 769 taps on 1024-point transforms (one wavefront
                               each) and up to 3073 taps on 4096-point transforms (four wavefronts).
-                              LIMIT: filter_len + peek <= 5120 taps for every method (the Levinson
-                              recursion keeps the two complex128 T-vectors it rewrites in the 160 KB of LDS;
-                              up to 3413 taps the autocorrelation sits there too, beyond it is read from a
-                              global workspace; above 3073 taps correlations and FIR run on the time-domain
-                              kernels); beyond that prc_ls_plan_create returns PRC_EUNSUPPORTED -- the reference
-                              (clutter_removal.py:109-160) accepts any length                         */
+                              Any filter_len + peek < n runs (the reference, clutter_removal.py:109-160,
+                              accepts any length): above 3073 taps correlations and FIR run on the time-domain
+                              kernels (the FIR in tap tiles beyond ~9000 taps); the Levinson recursion keeps
+                              its three complex128 T-vectors in LDS up to 3413 taps, the autocorrelation in a
+                              global workspace up to 5120, all three there beyond (seconds at 10^4 taps)       */
 } prc_ls_desc;
 
 typedef struct prc_ls_plan prc_ls_plan;
@@ -225,9 +224,10 @@ int prc_ls_set_profiling(prc_ls_plan* plan, int32_t enable);
 int prc_ls_get_profile(prc_ls_plan* plan, double* ms, int32_t* launches_per_kind);
 
 /* ---- NLMS_filter (clutter_removal.py:189-249) ---------------------------------------- */
-/* LIMIT: filter_len + peek <= 8192 taps (a stream's taps live in registers, 32 per lane: one wavefront up to 2048 taps,
- * a workgroup of two up to 4096, of four up to 8192); beyond that PRC_EUNSUPPORTED -- the reference
- * (clutter_removal.py:189-249) accepts any length.
+/* Any filter_len + peek < n runs (the reference, clutter_removal.py:189-249, takes any length): a stream's taps live in
+ * registers, 32 per lane -- one wavefront up to 2048 taps, a workgroup of two up to 4096, of four up to 8192; beyond that a
+ * plain kernel (one workgroup per stream, taps in a global workspace allocated for the call: microseconds per step, and
+ * the call synchronises `stream`).
  * nstreams independent sample-recursive filters, one wavefront (or one such workgroup) each.  taps_in: optional
  * complex64 [nstreams][T] initial taps (initialTaps), NULL = zeros.  taps_out: optional
  * complex64 [nstreams][T].  out: complex64, zero outside [filter_len, n-peek). */

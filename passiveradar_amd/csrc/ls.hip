@@ -218,16 +218,22 @@ __device__ __forceinline__ double wave_allsum_d(double v) {
 // C_GLOBAL (3414 .. 5120 taps, round 4): the autocorrelation c[] -- written once by the prologue, read-only in the
 // recursion -- lives in a global workspace (c_ws, [block][T]) instead of LDS, which then holds only the two vectors the
 // recursion rewrites (32 T bytes); its reads are ordinary cached loads behind one fence.
-template <bool C_GLOBAL>
+// MODE 2 (beyond 5120 taps, round 5: the reference takes any length): the two vectors the recursion rewrites live in a
+// global workspace as well (aw_ws, [block][2 T]); one wavefront per block still, its lanes' stores made visible to each
+// other's loads by one device-scope fence per step (write-through L1 + invalidate).  T^2 / 128 dependent global round
+// trips: seconds at 10^4 taps -- a fallback that works, not a fast path.
+template <int MODE>
 __global__ __launch_bounds__(64) void levinson_wave_kernel(const float2* __restrict__ partial,
                                                            int nblk, int T, double reg,
                                                            double2* __restrict__ taps_out,
-                                                           double2* __restrict__ rhs_ws, double2* __restrict__ c_ws) {
+                                                           double2* __restrict__ rhs_ws, double2* __restrict__ c_ws,
+                                                           double2* __restrict__ aw_ws) {
+    constexpr bool C_GLOBAL = MODE >= 1, A_GLOBAL = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double2* lds0 = reinterpret_cast<double2*>(smem_raw);
     const int b = blockIdx.x;
     double2* c = C_GLOBAL ? c_ws + (int64_t)b * T : lds0;
-    double2* a = C_GLOBAL ? lds0 : lds0 + T;
+    double2* a = A_GLOBAL ? aw_ws + (int64_t)b * 2 * T : (C_GLOBAL ? lds0 : lds0 + T);
     double2* w = a + T;
     const int lane = threadIdx.x;
     const float2* part = partial + (int64_t)b * nblk * 2 * T;
@@ -251,6 +257,7 @@ __global__ __launch_bounds__(64) void levinson_wave_kernel(const float2* __restr
     __syncthreads();                              // one wavefront: orders the LDS and the global writes above
     double err = c[0].x;
     if (lane == 0) w[0] = zdiv(bb[0], c[0]);
+    if (A_GLOBAL) __threadfence();
     __syncthreads();
     for (int m = 1; m < T; ++m) {
         const double2 bm = bb[m];                  // issued before the reductions: its latency sits under them
@@ -284,6 +291,7 @@ __global__ __launch_bounds__(64) void levinson_wave_kernel(const float2* __restr
                 w[mj] = zadd(w[mj], zmul(g, zconj(nj)));
             }
         }
+        if (A_GLOBAL) __threadfence();             // this step's a[], w[] reach memory before the next step's loads
         __builtin_amdgcn_wave_barrier();
     }
     for (int k = lane; k < T; k += 64) taps_out[(int64_t)b * T + k] = w[k];
@@ -782,26 +790,40 @@ struct FirArgs {
     int64_t ref_stride, srv_stride, out_stride;
     int64_t n;
     int32_t T, peek, circular, rot;
+    int32_t tile;          // taps per LDS tile (= T when the whole filter and its window fit the CU's LDS)
     PhaseRamp pr;
 };
 
 __global__ __launch_bounds__(LS_THREADS) void fir_subtract_kernel(FirArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* W = reinterpret_cast<float2*>(smem_raw);   // T
-    float2* Rt = W + a.T;                                // FIR_SPAN + T - 1
+    float2* W = reinterpret_cast<float2*>(smem_raw);   // tile
+    float2* Rt = W + a.tile;                             // FIR_SPAN + tile - 1
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int64_t n0 = (int64_t)blockIdx.x * FIR_SPAN;
     const float2* __restrict__ ref = a.ref + (int64_t)b * a.ref_stride;
     const float2* __restrict__ srv = a.srv + (int64_t)b * a.srv_stride;
     const double2* __restrict__ taps = a.taps + (int64_t)b * a.T;
-    for (int k = tid; k < a.T; k += LS_THREADS) {
-        const double2 t = taps[k];
+    // Double-precision accumulation.  A float32 accumulator over a long filter (1034 taps at config 3) loses 4e-6 of
+    // the INPUT level, which is 1e-3 of the hundred times smaller cleaned output (the reference's own complex64 matrix
+    // product has that error; the FFT kernels do not); float32 blocks of 16 summed in double still left 2.5e-4.  This is the
+    // fallback kernel (method = 1, or more taps than the FFT kernels carry): the products of the float32 taps and samples
+    // are formed and summed in double (fp64 FMA, half the fp32 rate) and the 1e-4 bar holds on the output (round 4).
+    double2 dacc[FIR_OPT];
+#pragma unroll
+    for (int o = 0; o < FIR_OPT; ++o) dacc[o] = make_double2(0.0, 0.0);
+    // taps k0 .. k0 + tk - 1 per pass (one pass up to ~9000 taps; longer filters -- the reference takes any -- in tiles):
+    // Rt[i] is reference sample n0 - k0 - halo + i, so tap k0 + k of output n0 + tid + o LS_THREADS reads Rl[o LS_THREADS - k]
+    for (int k0 = 0; k0 < a.T; k0 += a.tile) {
+    const int tk = a.T - k0 < a.tile ? a.T - k0 : a.tile;
+    if (k0) __syncthreads();                            // the previous tile's window is dead
+    for (int k = tid; k < tk; k += LS_THREADS) {
+        const double2 t = taps[k0 + k];
         W[k] = make_float2((float)t.x, (float)t.y);
     }
-    const int halo = a.T - 1;
+    const int halo = tk - 1;
     for (int i = tid; i < FIR_SPAN + halo; i += LS_THREADS) {
-        int64_t m = n0 - halo + i;
+        int64_t m = n0 - k0 - halo + i;
         float2 v = make_float2(0.f, 0.f);
         bool ok = m < a.n;
         if (m < 0) {
@@ -811,17 +833,9 @@ __global__ __launch_bounds__(LS_THREADS) void fir_subtract_kernel(FirArgs a) {
         Rt[i] = v;
     }
     __syncthreads();
-    // Double-precision accumulation.  A float32 accumulator over a long filter (1034 taps at config 3) loses 4e-6 of
-    // the INPUT level, which is 1e-3 of the hundred times smaller cleaned output (the reference's own complex64 matrix
-    // product has that error; the FFT kernels do not); float32 blocks of 16 summed in double still left 2.5e-4.  This is the
-    // fallback kernel (method = 1, or more taps than the FFT kernels carry): the products of the float32 taps and samples
-    // are formed and summed in double (fp64 FMA, half the fp32 rate) and the 1e-4 bar holds on the output (round 4).
-    double2 dacc[FIR_OPT];
-#pragma unroll
-    for (int o = 0; o < FIR_OPT; ++o) dacc[o] = make_double2(0.0, 0.0);
     const float2* Rl = Rt + tid + halo;
 #pragma unroll 2
-    for (int k = 0; k < a.T; ++k) {
+    for (int k = 0; k < tk; ++k) {
         const float2 wf = W[k];
         const double wx = (double)wf.x, wy = (double)wf.y;
 #pragma unroll
@@ -833,6 +847,7 @@ __global__ __launch_bounds__(LS_THREADS) void fir_subtract_kernel(FirArgs a) {
             dacc[o].y = fma(wx, ry, dacc[o].y);
             dacc[o].y = fma(wy, rx, dacc[o].y);
         }
+    }
     }
 #pragma unroll
     for (int o = 0; o < FIR_OPT; ++o) {
@@ -857,7 +872,8 @@ struct prc_ls_plan {
     float2* d_partial = nullptr;
     double2* d_taps = nullptr;
     double2* d_rhs = nullptr;      // right-hand sides of the per-bin Levinson solve, [block][T] (one element read per step)
-    double2* d_cws = nullptr;      // autocorrelations of that solve beyond 3413 taps, [block][T] (levinson_wave_kernel<true>)
+    double2* d_cws = nullptr;      // autocorrelations of that solve beyond 3413 taps, [block][T] (levinson_wave_kernel<1>, <2>)
+    double2* d_aws = nullptr;      // predictor and taps of that solve beyond 5120 taps, [block][2 T] (levinson_wave_kernel<2>)
     float2* d_tmp[2] = {nullptr, nullptr};
     // shared-inverse path (non-circular FFT chain): c_0, S_e, dense T_0^{-1} per block
     double2* d_c0 = nullptr;
@@ -884,6 +900,7 @@ extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_rhs) (void)hipFree(p->d_rhs);
     if (p->d_cws) (void)hipFree(p->d_cws);
+    if (p->d_aws) (void)hipFree(p->d_aws);
     if (p->d_tmp[0]) (void)hipFree(p->d_tmp[0]);
     if (p->d_tmp[1]) (void)hipFree(p->d_tmp[1]);
     if (p->d_c0) (void)hipFree(p->d_c0);
@@ -898,10 +915,19 @@ extern "C" int prc_ls_plan_destroy(prc_ls_plan* p) {
     return PRC_OK;
 }
 
-// c, a, w in LDS up to 3413 taps; beyond that c moves to a global workspace (levinson_wave_kernel<true>) and a, w stay: 5120
-static bool levinson_c_global(int T) { return sizeof(double2) * ((size_t)3 * T) > 160 * 1024; }
-static size_t levinson_lds(int T) { return sizeof(double2) * ((size_t)(levinson_c_global(T) ? 2 : 3) * T); }
-static size_t fir_lds(int T) { return sizeof(float2) * ((size_t)T + FIR_SPAN + T - 1); }
+// c, a, w in LDS up to 3413 taps (mode 0); beyond that c moves to a global workspace and a, w stay (mode 1: 5120 taps);
+// beyond that all three are global (mode 2: any length, slowly)
+static int levinson_mode(int T) {
+    return sizeof(double2) * ((size_t)3 * T) <= 160 * 1024 ? 0 : (sizeof(double2) * ((size_t)2 * T) <= 160 * 1024 ? 1 : 2);
+}
+static bool levinson_c_global(int T) { return levinson_mode(T) >= 1; }
+static size_t levinson_lds(int T) { const int m = levinson_mode(T); return m == 2 ? 0 : sizeof(double2) * ((size_t)(m == 1 ? 2 : 3) * T); }
+// time-domain FIR: the taps of one pass and the window they meet stay within 150 KB of LDS
+static int fir_tile(int T) {
+    const int cap = (int)((150 * 1024 / sizeof(float2) - FIR_SPAN) / 2);
+    return T < cap ? T : cap;
+}
+static size_t fir_lds(int T) { const size_t t = (size_t)fir_tile(T); return sizeof(float2) * (t + FIR_SPAN + t - 1); }
 
 // allow_cache = false: the retry after a mandatory allocation failed while the (optional) spectrum cache was held --
 // the same plan without the cache, i.e. on the kernels that recompute the spectra
@@ -913,8 +939,6 @@ static int ls_plan_create_impl(prc_ls_plan** plan, const prc_ls_desc* d, bool al
     const int T = d->filter_len + d->peek;
     PRC_REQUIRE(T < d->n, PRC_EINVAL, "prc_ls_plan_create: filter_len+peek (%d) >= n (%lld)", T,
                 (long long)d->n);
-    PRC_REQUIRE(levinson_lds(T) <= 160 * 1024, PRC_EUNSUPPORTED,
-                "prc_ls_plan_create: %d taps exceed the Levinson solver (two complex128 T-vectors in the 160 KB of LDS: max 5120)", T);
     prc_ls_plan* p = new prc_ls_plan();
     p->desc = *d;
     p->T = T;
@@ -1006,12 +1030,13 @@ static int ls_plan_create_impl(prc_ls_plan** plan, const prc_ls_desc* d, bool al
             e = hipFuncSetAttribute((const void*)ls_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)levinson_wave_kernel<false>,
+        e = hipFuncSetAttribute((const void*)levinson_wave_kernel<0>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)levinson_wave_kernel<true>,
+        e = hipFuncSetAttribute((const void*)levinson_wave_kernel<1>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess && levinson_c_global(T)) e = hipMalloc(&p->d_cws, sizeof(double2) * (size_t)d->max_blocks * T);
+    if (e == hipSuccess && levinson_mode(T) == 2) e = hipMalloc(&p->d_aws, sizeof(double2) * (size_t)d->max_blocks * 2 * T);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)fir_subtract_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1240,12 +1265,19 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
             }
             if (rc) return rc;
             if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 1], stream));
-            if (levinson_c_global(T))
-                hipLaunchKernelGGL(levinson_wave_kernel<true>, dim3(nblocks), dim3(64), levinson_lds(T), stream,
-                                   p->d_partial, p->nblk, T, reg, p->d_taps, p->d_rhs, p->d_cws);
-            else
-                hipLaunchKernelGGL(levinson_wave_kernel<false>, dim3(nblocks), dim3(64), levinson_lds(T), stream,
-                                   p->d_partial, p->nblk, T, reg, p->d_taps, p->d_rhs, (double2*)nullptr);
+            switch (levinson_mode(T)) {
+                case 2:
+                    hipLaunchKernelGGL(levinson_wave_kernel<2>, dim3(nblocks), dim3(64), 0, stream,
+                                       p->d_partial, p->nblk, T, reg, p->d_taps, p->d_rhs, p->d_cws, p->d_aws);
+                    break;
+                case 1:
+                    hipLaunchKernelGGL(levinson_wave_kernel<1>, dim3(nblocks), dim3(64), levinson_lds(T), stream,
+                                       p->d_partial, p->nblk, T, reg, p->d_taps, p->d_rhs, p->d_cws, (double2*)nullptr);
+                    break;
+                default:
+                    hipLaunchKernelGGL(levinson_wave_kernel<0>, dim3(nblocks), dim3(64), levinson_lds(T), stream,
+                                       p->d_partial, p->nblk, T, reg, p->d_taps, p->d_rhs, (double2*)nullptr, (double2*)nullptr);
+            }
             PRC_LAUNCH_CHECK();
             if (p->profiling) PRC_HIP(hipEventRecord(p->ev[4 * ib + 2], stream));
             if (p->method == 2) {
@@ -1263,6 +1295,7 @@ extern "C" int prc_ls_execute(prc_ls_plan* p, const void* ref, const void* srv, 
                 fa.circular = p->desc.circular;
                 fa.rot = pr.enabled;
                 fa.pr = pr;
+                fa.tile = fir_tile(T);
                 dim3 grid((unsigned)ceil_div64(n, FIR_SPAN), (unsigned)nblocks);
                 hipLaunchKernelGGL(fir_subtract_kernel, grid, dim3(LS_THREADS), fir_lds(T), stream, fa);
                 PRC_LAUNCH_CHECK();

@@ -285,6 +285,77 @@ __global__ __launch_bounds__(64 * (NW > 1 ? NW : MAXW)) void nlms_kernel(NlmsArg
     }
 }
 
+
+// ---- any filter length (round 5) ---------------------------------------------------------------------------------------
+// Beyond the 8192 taps the register-resident kernels hold, the reference (clutter_removal.py:189-249 takes any length)
+// is served by the plain form: one workgroup of 1024 threads per stream, the taps in a global workspace (thread t owns
+// taps t, t + 1024, ...: nobody else ever touches them), per step a block-wide reduction of conj(w).u and u^H u in
+// double and the update.  Two workgroup barriers and ~2 T / 1024 global reads per thread and step: microseconds per step
+// -- a fallback that works at any length, not a fast path.
+#define NLG_THREADS 1024
+__device__ __forceinline__ double nlg_wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__global__ __launch_bounds__(NLG_THREADS) void nlms_generic_kernel(NlmsArgs a, float2* __restrict__ wbuf) {
+    __shared__ double red[2][3][NLG_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float2* __restrict__ ref = a.ref + (int64_t)b * a.stride;
+    const float2* __restrict__ srv = a.srv + (int64_t)b * a.stride;
+    float2* __restrict__ out = a.out + (int64_t)b * a.out_stride;
+    float2* __restrict__ w = wbuf + (int64_t)b * a.T;
+    const int T = a.T;
+    const int64_t nsteps = a.n - T;
+    for (int i = tid; i < T; i += NLG_THREADS) w[i] = a.taps_in ? a.taps_in[(int64_t)b * T + i] : make_float2(0.f, 0.f);
+    for (int64_t i = tid; i < a.n; i += NLG_THREADS)
+        if (i < a.L || i >= a.L + (nsteps > 0 ? nsteps : 0)) out[i] = make_float2(0.f, 0.f);      // :231
+    for (int64_t k = 0; k < nsteps; ++k) {
+        const float2* top = ref + T + k;                          // u[i] = top[-i]   (:211-215)
+        double yr = 0.0, yi = 0.0, en = 0.0;
+        for (int i = tid; i < T; i += NLG_THREADS) {
+            const float2 u = top[-i], wv = w[i];
+            yr += (double)(wv.x * u.x + wv.y * u.y);             // conj(w) u
+            yi += (double)(wv.x * u.y - wv.y * u.x);
+            en += (double)u.x * (double)u.x + (double)u.y * (double)u.y;
+        }
+        yr = nlg_wave_sum(yr);
+        yi = nlg_wave_sum(yi);
+        en = nlg_wave_sum(en);
+        const int par = (int)(k & 1);                             // two slot sets: a fast wavefront may already write step k + 1's
+        if (lane == 0) {
+            red[par][0][wave] = yr;
+            red[par][1][wave] = yi;
+            red[par][2][wave] = en;
+        }
+        __syncthreads();
+        double sr = 0.0, si = 0.0, se = 0.0;
+#pragma unroll
+        for (int q = 0; q < NLG_THREADS / 64; ++q) {              // the same order in every thread: one error sample for all
+            sr += red[par][0][q];
+            si += red[par][1][q];
+            se += red[par][2][q];
+        }
+        const float2 d = srv[k + a.L];
+        const float er = d.x - (float)sr, ei = d.y - (float)si;
+        const float enf = (float)se;
+        for (int i = tid; i < T; i += NLG_THREADS) {
+            const float2 u = top[-i];
+            // w += (mu u) conj(e) / (u^H u), float32 as the reference's complex64 arithmetic (:214)
+            const float mx = a.mu * u.x, my = a.mu * u.y;
+            float2 wv = w[i];
+            wv.x += (mx * er + my * ei) / enf;
+            wv.y += (my * er - mx * ei) / enf;
+            w[i] = wv;
+        }
+        if (tid == 0) out[a.L + k] = make_float2(er, ei);
+        // no second barrier: the next step's partial sums go to the other slot set, and a thread rewrites only its own taps
+    }
+    if (a.taps_out)
+        for (int i = tid; i < T; i += NLG_THREADS) a.taps_out[(int64_t)b * T + i] = w[i];
+}
+
 extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int64_t stride,
                                 int32_t filter_len, int32_t peek, float mu, const void* taps_in,
                                 void* out, int64_t out_stride, void* taps_out, int32_t nstreams,
@@ -295,8 +366,35 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
                 "prc_nlms_execute: non-positive size");
     PRC_REQUIRE(stride >= n && out_stride >= n, PRC_ESHAPE, "prc_nlms_execute: stride shorter than n");
     const int T = filter_len + peek;
-    PRC_REQUIRE(T <= 8192, PRC_EUNSUPPORTED,
-                "prc_nlms_execute: %d taps exceed the four-wavefront kernel (max 8192)", T);
+    if (T > 8192) {
+        // the plain form for any length; its tap workspace lives for the call, so this path synchronises the stream
+        NlmsArgs g;
+        g.ref = (const float2*)ref;
+        g.srv = (const float2*)srv;
+        g.taps_in = (const float2*)taps_in;
+        g.out = (float2*)out;
+        g.taps_out = (float2*)taps_out;
+        g.n = n;
+        g.stride = stride;
+        g.out_stride = out_stride;
+        g.L = filter_len;
+        g.peek = peek;
+        g.T = T;
+        g.mu = mu;
+        g.nstreams = nstreams;
+        g.kt = 0;
+        float2* wbuf = nullptr;
+        PRC_HIP(hipMalloc(&wbuf, sizeof(float2) * (size_t)nstreams * T));
+        hipLaunchKernelGGL(nlms_generic_kernel, dim3(nstreams), dim3(NLG_THREADS), 0, (hipStream_t)stream, g, wbuf);
+        const hipError_t le = hipGetLastError();
+        const hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(wbuf);
+        if (le != hipSuccess || se != hipSuccess) {
+            prc_set_error("prc_nlms_execute: the any-length kernel failed: %s", hipGetErrorString(le != hipSuccess ? le : se));
+            return PRC_EHIP;
+        }
+        return PRC_OK;
+    }
     int nwave = T <= 2048 ? 1 : (T <= 4096 ? 2 : 4);             // wavefronts per stream
     // latency experiments (tools/nlms_waves_probe.py): PRC_OPT_NLMS_WAVES = 2 or 4 splits a filter that fits one wavefront
     // over 2 or 4 as well (honoured for the config-3 filter length, T = 1034, which is what the multi-wavefront

@@ -123,7 +123,9 @@ def worker(wseed):
           note("caf", rel(fast_xambg(ref, srv, R, F, N, w), O.fast_xambg(ref, srv, R, F, N, w)), 2e-5, ("caf", N, R, F, win))
       elif k == 1:    # LS Toeplitz / direct
           N = int(rng.integers(300, 30000)); L = int(rng.integers(1, min(200, N // 8))); peek = int(rng.integers(0, 12))
-          ref, srv = scene.make_scene(N, 1e4, max(L, 50), int(rng.integers(1 << 30)))
+          if rng.random() < 0.03:         # beyond 5120 taps: the Levinson recursion out of a global workspace (any length)
+              L = int(rng.integers(5111, 6500)); N = 3 * L + int(rng.integers(100, 4000))
+          ref, srv = scene.make_scene(N, 1e4, max(min(L, 200), 50), int(rng.integers(1 << 30)))
           if rng.random() < 0.5:
               got, gt = LS_Filter_Toeplitz(ref, srv, L, peek, True); exp, et = O.LS_Filter_Toeplitz(ref, srv, L, peek, True)
               note("ls_toeplitz", max(rel(got, exp), rel(gt, et)), 1e-4, ("toep", N, L, peek))
@@ -141,6 +143,8 @@ def worker(wseed):
           N = int(rng.integers(200, 6000)); L = int(rng.integers(1, 2030)); mu = float(rng.choice([0.01, 0.05, 0.2]))
           if rng.random() < 0.2:          # two / four wavefronts per stream (2049 .. 8192 taps)
               L = int(rng.integers(2030, 8180)); N = L + 10 + int(rng.integers(50, 1200))
+          elif rng.random() < 0.05:       # beyond the register-resident kernels: the any-length fallback
+              L = int(rng.integers(8183, 11000)); N = L + 10 + int(rng.integers(50, 600))
           ref, srv = scene.make_scene(N, 1e4, 50, int(rng.integers(1 << 30)))
           note("nlms", rel(NLMS_filter(ref, srv, L, mu), c_oracle.nlms(ref, srv, L, mu)[0]) if N > L + 10 else 0.0, 1e-4, ("nlms", N, L, mu))
       elif k == 4:    # xcorr

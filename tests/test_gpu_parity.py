@@ -401,11 +401,22 @@ def test_nlms_long_filters_vs_reference_golden(T):
     assert rel_err(out, g["out"]) < TOL and rel_err(taps, g["taps"]) < TOL
 
 
-def test_nlms_documented_tap_limit():
+@pytest.mark.parametrize("L,warm", [(8190, False), (12000, True), (20011, False)])
+def test_nlms_of_any_length(L, warm):
+    """beyond the 8192 taps of the register-resident kernels (round 5; the reference takes any length,
+    clutter_removal.py:189-249): one workgroup per stream, taps in a global workspace, block-wide reductions in double
+    -- a slow fallback held to the same bar against the C twin, cold and warm start, two streams in one launch"""
+    from oracle import c_oracle
     from passiveradar_amd.clutter_removal import NLMS_filter
-    ref, srv = scene.make_scene(9000, 1e4, 50, 5)
-    with pytest.raises(NotImplementedError):
-        NLMS_filter(ref, srv, 8190, 0.05, 10)                   # T = 8200 > 8192
+    n = L + 10 + 900
+    ref, srv = scene.make_scene(n, 1e4, 50, 9000 + L)
+    t0 = None
+    if warm:
+        rng = np.random.default_rng(L)
+        t0 = ((rng.standard_normal(L + 10) + 1j * rng.standard_normal(L + 10)) * 1e-3).astype(np.complex64)
+    out, taps = NLMS_filter(ref, srv, L, 0.05, 10, t0, True)
+    exp, etaps = c_oracle.nlms(ref, srv, L, 0.05, 10, t0)
+    assert taps.shape == (L + 10,) and rel_err(out, exp) < TOL and rel_err(taps, etaps) < TOL
 
 
 @pytest.mark.parametrize("tail", [1, 5, 9, 10])
@@ -660,8 +671,6 @@ def test_ls_up_to_the_3073_taps_of_the_team_kernels(L):
     exp, etaps = O.LS_Filter_Toeplitz(ref, srv, L, return_filter=True)
     out, taps = LS_Filter_Toeplitz(ref, srv, L, return_filter=True)
     assert rel_err(taps, etaps) < TIGHT and rel_err(out, exp) < TIGHT
-    with pytest.raises(NotImplementedError):
-        LS_Filter_Toeplitz(ref, srv, 5200)                     # documented limit: 5120 taps
 
 
 def test_ls_beyond_the_lds_resident_solver():
@@ -674,6 +683,23 @@ def test_ls_beyond_the_lds_resident_solver():
     exp, etaps = O.LS_Filter_Toeplitz(ref, srv, L, return_filter=True)
     out, taps = LS_Filter_Toeplitz(ref, srv, L, return_filter=True)
     assert rel_err(taps, etaps) < TIGHT and rel_err(out, exp) < TOL
+
+
+@pytest.mark.parametrize("L,circular", [(5200, False), (9500, False), (5500, True)])
+def test_ls_of_any_length(L, circular):
+    """beyond 5120 taps (round 5; the reference accepts any length, clutter_removal.py:6-56, :109-160): the Levinson
+    recursion with all three of its vectors in a global workspace (one wavefront per block, a device-scope fence per step)
+    and, beyond ~9000 taps, the time-domain FIR in tap tiles -- slow fallbacks, held to the same bar"""
+    from passiveradar_amd.clutter_removal import LS_Filter, LS_Filter_Toeplitz
+    n = 3 * L + 5000
+    ref, srv = scene.make_scene(n, 1.0e7, 200, 7000 + L)
+    if circular:
+        exp, etaps = O.LS_Filter(ref, srv, L, return_filter=True)
+        out, taps = LS_Filter(ref, srv, L, return_filter=True)
+    else:
+        exp, etaps = O.LS_Filter_Toeplitz(ref, srv, L, return_filter=True)
+        out, taps = LS_Filter_Toeplitz(ref, srv, L, return_filter=True)
+    assert taps.shape == (L + 10,) and rel_err(taps, etaps) < 1e-5 and rel_err(out, exp) < TOL
 
 
 def test_ls_t1034_long_block_vs_oracle(ls_method):
