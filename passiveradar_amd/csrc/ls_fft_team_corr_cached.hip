@@ -107,7 +107,9 @@ __global__ __launch_bounds__(FT_THREADS, 2) void ls_corr_cached_team_kernel(LsFf
             for (int m = 0; m < 8; ++m)
                 cp[FT_THREADS * m + t] = make_float4(x[2 * m].x, x[2 * m].y, x[2 * m + 1].x, x[2 * m + 1].y);
         }
-        ft4096_fwd<1>(up, f);
+#ifndef LTC_EXP_NOUP                  // timing ablation, never shipped: without the reference piece's transform (an upper
+        ft4096_fwd<1>(up, f);         // bound for what pruning it -- FFT(piece) = X_p - FFT(history) -- could save)
+#endif
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             float2 w = Wrr[FT_THREADS * m];
