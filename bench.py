@@ -22,13 +22,22 @@ Workloads (BASELINE.json configs):
   prconfig       the reference's published workload (README.md:24, PRconfig.yaml as shipped) from raw int8 in host
                  memory to maps + CFAR back in host memory (and once more with the zarr store): its own JSON line.
 
-One JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     : dominant kernel's algorithmic bytes (or flops) / its average launch time (HIP events on
-                 the launch stream), against the 8 TB/s HBM peak (or the 157.3 TFLOP/s fp32 vector peak
-                 for the serial NLMS recursion, which is VALU-issue-bound)
-  cpu_baseline : the reference's CPU path (oracle restatement issuing the same NumPy/SciPy calls,
-                 SciPy-1.15 np.roots artefact left out) MEASURED on this box's host cores: one core,
-                 and one frame per worker process on min(cores, 32) workers (rank 0, N=1 only)
+`--gpus N` with N > 1 and no launcher around it starts the N ranks itself (torch.distributed.run on 127.0.0.1) and refuses
+to run when the host has fewer GPUs; under a launcher it checks WORLD_SIZE against N.
+
+One JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline     : the dominant kernel's rate on the HBM bytes it MOVED (2 x FETCH_SIZE + WRITE_SIZE of this run's own
+                 rocprofv3 --pmc child passes; the committed per-unit figures or the analytic bytes when they cannot run --
+                 `frac_basis` says which) over its average launch time (HIP events on the launch stream, kernel alone),
+                 against the 8 TB/s HBM peak; SURVEY 8d's two-pass algorithmic accounting, which credits a fused kernel with
+                 bytes it does not move, is reported as `frac_two_pass_accounting`; `frac_in_step` is the same kernel inside
+                 the overlapped step.  (NLMS: flops against the 157.3 TFLOP/s fp32 vector peak -- VALU-issue-bound.)
+  kernels      : per kernel family the solo launch time, the duration inside the overlapped step (kernel-trace child pass)
+                 and the bytes moved; kernel_time_accounting relates their sums to ms_per_step
+  cpu_baseline : the reference's CPU path (oracle restatement issuing the same NumPy/SciPy calls, SciPy-1.15 np.roots
+                 artefact left out) MEASURED on this box's host cores: one core, and one frame per worker process on EVERY
+                 usable core (then halved while the workers slow each other down: `value` is the strongest leg)
+  secondary    : BASELINE configs 3 and 5, a few steps each in child processes (default single-GPU line only)
 """
 import argparse
 import json
@@ -134,6 +143,10 @@ def _cpu_frame_worker(args):
     ref, srv = scene.make_scene(n, fs, R, scene.scene_seed(2) + seed_off)
     w = get_window(("kaiser", 5.0), n)
     C = n // 2
+    # lazy imports and first-call set-up of SciPy (resample_poly, correlate, solve_toeplitz) stay out of the clock
+    O.fast_xambg_libcalls(ref[:4096], srv[:4096], 3, 16, w[:4096])
+    if clutter == "ls":
+        O.LS_Filter_Multiple_libcalls(ref[:4096], srv[:4096], 8, fs, [0, 1])
     t0 = time.perf_counter()
     O.fast_xambg_libcalls(ref, srv, lags, F, w)
     t_caf = (time.perf_counter() - t0) * (R + 1) / (lags + 1)
@@ -151,53 +164,158 @@ def _cpu_frame_worker(args):
     return t_caf, t_cl
 
 
-def cpu_baseline(workload, max_workers=32, asis=False):
-    """(i) one core, bounded sample; (ii) one frame per worker process on min(cores, max_workers) workers."""
+def _usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def _host_memory_budget():
+    """bytes this process tree may use: the smaller of MemAvailable and what the cgroup (v2 or v1) still allows"""
+    avail = None
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            v = open(lim).read().strip()
+            if v != "max" and int(v) < (1 << 60):
+                room = int(v) - int(open(cur).read().strip())
+                avail = room if avail is None else min(avail, room)
+        except (OSError, ValueError):
+            pass
+    return avail
+
+
+def cpu_baseline(workload, max_workers=None, asis=False):
+    """(i) one core, bounded sample; (ii) one frame per worker process on every usable host core (the x50 claim
+    is against the all-cores number), fewer only when ``max_workers`` says so or host memory would not hold them."""
     import multiprocessing as mp
     fs, n, R, F, clutter, _ = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
+    cores = _usable_cores()
     nill = N_ILLUMINATORS.get(workload, 1)
     # bounded one-core sample: 64 of the lag columns (whole LS hop), scaled to the full lag count
     lags1 = min(R, 63)
-    t_caf1, t_cl1 = _cpu_frame_worker((workload, lags1, 0))
-    one = 1.0 / (nill * t_caf1 + t_cl1)
-    W = max(1, min(cores, max_workers))
-    lagsW = R if workload in ("cfg2", "cfg2p2", "cfg1", "cfg4") else min(R, 63)   # whole frames where they take < 1 min
+    W = max(1, cores if max_workers is None else min(cores, max_workers))
+    # a worker holds its frame (ref, srv complex64, window float64) and fast_xambg's per-lag temporaries; measured peak
+    # RSS at config 2: 296 MB (interpreter + NumPy/SciPy ~100 MB of it).  Bound: six N-sample complex128 arrays + 150 MB,
+    # and the workers together may take half of what the host has free
+    per_worker = 96.0 * n + 1.5e8
+    budget = _host_memory_budget()
+    mem_note = ""
+    if budget is not None and W * per_worker > 0.5 * budget:
+        W_mem = max(1, int(0.5 * budget // per_worker))
+        mem_note = f"; {W} usable cores, capped to {W_mem} workers by host memory ({budget / 2**30:.0f} GiB free)"
+        W = min(W, W_mem)
+    # whole frames up to 64 workers; beyond, a quarter of the lag columns, scaled (the cost per column does not depend on the
+    # column) so that a leg stays well under a minute even when memory bandwidth stretches every worker
     ctx = mp.get_context("spawn")
-    t0 = time.perf_counter()
-    with ctx.Pool(W) as pool:
-        per = pool.map(_cpu_frame_worker, [(workload, lagsW, i) for i in range(W)])
-    wall = time.perf_counter() - t0
-    # every worker did one frame's worth of (scaled) work concurrently; throughput = W / the slowest worker
-    slow = max(nill * a + b for a, b in per)
-    allc = W / slow
+    # one thread per worker: the variables must be in the environment the children START with (their NumPy / OpenBLAS load
+    # before any code of ours runs in them; round 3's 256-worker leg set them too late and measured 0.55 frames/s against
+    # 2.2 on 32 workers)
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved:
+        os.environ[k] = "1"
+    legs = []
+    # the one-core sample runs in a worker process of its own as well: in THIS process NumPy's BLAS is already up with
+    # one thread per core (np.correlate's dot products would not be a one-core figure)
+    with ctx.Pool(1) as pool1:
+        t_caf1, t_cl1 = pool1.map(_cpu_frame_worker, [(workload, lags1, 0)])[0]
+    one = 1.0 / (nill * t_caf1 + t_cl1)
+
+    def leg(Wl):
+        whole = workload in ("cfg2", "cfg2p2", "cfg1", "cfg4") and Wl <= 64
+        lagsW = R if whole else min(R, 63)
+        t0 = time.perf_counter()
+        pool = ctx.Pool(Wl)
+        try:
+            per = pool.map_async(_cpu_frame_worker, [(workload, lagsW, i) for i in range(Wl)], chunksize=1).get(timeout=420)
+            pool.close()
+        except mp.TimeoutError:
+            pool.terminate()
+            legs.append({"workers": Wl, "error": "timed out after 420 s"})
+            return None
+        finally:
+            pool.join()
+        wall = time.perf_counter() - t0
+        # every worker did one frame's worth of (scaled) work concurrently; throughput = workers / the slowest worker
+        slow = max(nill * a_ + b_ for a_, b_ in per)
+        rec = {"workers": Wl, "value": Wl / slow, "lag_columns_timed": lagsW + 1, "wall_seconds": wall,
+               "slowest_worker_frame_seconds": slow, "fastest_worker_frame_seconds": min(nill * a_ + b_ for a_, b_ in per),
+               "slowdown_vs_one_core": slow * one}
+        legs.append(rec)
+        return rec
+    try:
+        # all usable cores first (SURVEY 8d); when the workers get in each other's way (a frame takes more than 1.5 x its
+        # one-core time: memory bandwidth, SMT siblings) fewer workers may be the STRONGER baseline, so halve until the
+        # throughput stops growing -- `value` is the best leg, every leg is listed
+        Wl, best = W, None
+        while True:
+            rec = leg(Wl)
+            if rec is not None and (best is None or rec["value"] > best["value"]):
+                best = rec
+            elif rec is not None and best is not None:
+                break                                     # fewer workers were slower: the maximum is behind us
+            if Wl <= 16 or (rec is not None and rec["slowdown_vs_one_core"] < 1.5):
+                break
+            Wl = max(16, Wl // 2)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if best is None:
+        best = {"workers": 1, "value": one, "lag_columns_timed": lags1 + 1, "wall_seconds": 0.0,
+                "slowest_worker_frame_seconds": 1.0 / one, "fastest_worker_frame_seconds": 1.0 / one, "slowdown_vs_one_core": 1.0}
     note_cl = {"ls": "1 LS_Filter_Multiple hop (5 bins)", "nlms": "NLMS on 20k samples (C twin), scaled to one hop",
                None: "no canceller"}[clutter]
     return {
-        "value": allc, "unit": "frames/s", "cores": W, "kind": "port",
-        "sample": f"{W} worker processes x 1 frame each, concurrently ({lagsW + 1} of {R + 1} lag columns timed per "
-                  f"fast_xambg, scaled; {note_cl}; 1 thread per process); NumPy/SciPy calls of the reference, "
-                  f"np.roots artefact bypassed",
+        "value": best["value"], "unit": "frames/s", "cores": best["workers"], "kind": "port",
+        "sample": f"{best['workers']} worker processes x 1 frame each, concurrently ({best['lag_columns_timed']} of {R + 1} lag "
+                  f"columns timed per fast_xambg, scaled; {note_cl}; 1 thread per process); NumPy/SciPy calls of the reference, "
+                  f"np.roots artefact bypassed; the strongest of the legs listed under `legs` (all usable cores first){mem_note}",
         "one_core_value": one, "one_core_caf_seconds": t_caf1, "one_core_clutter_seconds": t_cl1,
         "one_core_sample": f"{lags1 + 1} of {R + 1} lag columns + {note_cl}",
-        "host_cores": cores, "workers": W, "workers_wall_seconds": wall,
-        "slowest_worker_frame_seconds": slow,
+        "host_cores": os.cpu_count() or 1, "usable_cores": cores, "workers": best["workers"], "legs": legs,
+        "all_usable_cores_value": legs[0].get("value") if legs else None,
+        "workers_wall_seconds": best["wall_seconds"], "slowest_worker_frame_seconds": best["slowest_worker_frame_seconds"],
     }
 
 
 KERNEL_FAMILY = {"caf_segments": ("caf_fft_kernel", "caf_fft_team_kernel", "caf_fft_team_multi_kernel", "caf_direct_kernel"),
                  "caf_doppler": ("doppler_col_kernel", "shift_transpose_kernel", "transpose_jk_kj_kernel"),
                  "ls_correlate": ("ls_corr_cached_kernel", "ls_corr_cached_team_kernel"),
-                 "ls_fir_subtract": ("ls_fused_cached_kernel", "ls_fused_cached_team_kernel")}
+                 "ls_fir_subtract": ("ls_fused_cached_kernel", "ls_fused_cached_team_kernel"),
+                 "ls_solve": ("ls_solve_gs_kernel", "ls_prepare_kernel"),
+                 "nlms": ("nlms_kernel", "nlms_generic_kernel")}
 
 
-def measure_traffic(wl, family, frames, extra_args=(), timeout=150):
-    """roofline.traffic MEASURED by this run (it used to be a constant from a file): two child runs of this
-    script under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters only, no trace domain, as
-    MI355X_MICROARCH.md prescribes -- on ``frames`` frames of the same workload (one launch of the dominant kernel covers
-    as many units as in the timed run), stages back to back on one stream.  Returns (bytes per launch of the kernel family
-    = 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of the guide for wide coalesced reads, averaged over the launches
-    with the largest grid; a note) or (None, why not)."""
+def _kernel_family(name):
+    k = name.replace("void ", "").split("(")[0].split("<")[0].strip()
+    for fam, names in KERNEL_FAMILY.items():
+        if k in names:
+            return fam, k
+    return None, k
+
+
+def _child_cmd(wl, frames, steps, warmup, extra_args):
+    return [sys.executable, os.path.join(REPO, "bench.py"), "--workload", wl, "--frames", str(frames), "--steps", str(steps),
+            "--warmup", str(warmup), "--no-cpu", "--traffic", "none", "--secondary", "none", "--in-step", "none", "--no-kernel-timing"] + list(extra_args)
+
+
+def measure_traffic(wl, frames, extra_args=(), timeout=150):
+    """HBM bytes per launch of EVERY kernel family of the step, MEASURED by this run: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, counters only, no trace domain, as
+    MI355X_MICROARCH.md prescribes -- on ``frames`` frames of the same workload (one launch of a kernel covers as many
+    units as in the timed run), stages back to back on one stream.  Returns ({family: 2 x FETCH_SIZE + WRITE_SIZE per
+    launch (the guide's gfx950 correction for wide coalesced reads), summed over the kernels of a family that follow one
+    another within a stage (prepare + solve), averaged over the launches with the largest grid}, note) or (None, why not)."""
     import csv
     import glob
     import shutil
@@ -205,39 +323,118 @@ def measure_traffic(wl, family, frames, extra_args=(), timeout=150):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
-    names = KERNEL_FAMILY.get(family)
-    if not names:
-        return None, f"no counter family for {family}"
     got = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="prc_pmc_", dir="/tmp")
         try:
-            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
-                   os.path.join(REPO, "bench.py"), "--workload", wl, "--frames", str(frames), "--steps", "1", "--warmup", "1",
-                   "--no-cpu", "--no-overlap", "--traffic", "none"] + list(extra_args)
+            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + \
+                _child_cmd(wl, frames, 1, 1, ["--no-overlap"] + list(extra_args))
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {ctr} child failed (rc {r.returncode})"
-            vals = []
+            vals = {}
             for fcsv in files:
                 for row in csv.DictReader(open(fcsv)):
-                    k = row["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0]
-                    if row["Counter_Name"] == ctr and k in names:
-                        vals.append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+                    fam, k = _kernel_family(row["Kernel_Name"])
+                    if row["Counter_Name"] == ctr and fam:
+                        vals.setdefault((fam, k), []).append((int(row["Grid_Size"]), float(row["Counter_Value"])))
             if not vals:
-                return None, f"no {family} launch in the --pmc {ctr} pass"
-            big = max(g for g, _ in vals)
-            sel = [v for g, v in vals if g == big]
-            got[ctr] = sum(sel) / len(sel) * 1e3                     # rocprofv3 reports KB
+                return None, f"no library kernel in the --pmc {ctr} pass"
+            got[ctr] = {}
+            for (fam, k), v in vals.items():
+                big = max(g for g, _ in v)
+                sel = [x for g, x in v if g == big]
+                got[ctr][(fam, k)] = sum(sel) / len(sel) * 1e3            # rocprofv3 reports KB
+            # every library launch of the child belongs to one of its two steps (--no-kernel-timing)
+            got[ctr + "_all"] = sum(x for v in vals.values() for _, x in v) * 1e3 / (2.0 * frames)
         except Exception as e:                                       # noqa: BLE001 -- a measurement aid must never take the line down
             return None, f"--pmc {ctr} pass: {e!r}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], (
-        f"measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of bench.py --workload {wl} "
-        f"--frames {frames} --no-overlap, 2 x FETCH_SIZE + WRITE_SIZE per launch (FETCH {got['FETCH_SIZE'] / 1e6:.1f} MB x 2, "
-        f"WRITE {got['WRITE_SIZE'] / 1e6:.1f} MB)")
+    out, parts = {}, {}
+    out["_per_frame_total"] = 2.0 * got["FETCH_SIZE_all"] + got["WRITE_SIZE_all"]
+    for key in set(got["FETCH_SIZE"]) | set(got["WRITE_SIZE"]):
+        f_, w_ = got["FETCH_SIZE"].get(key, 0.0), got["WRITE_SIZE"].get(key, 0.0)
+        out[key[0]] = out.get(key[0], 0.0) + 2.0 * f_ + w_
+        p = parts.setdefault(key[0], [0.0, 0.0])
+        p[0] += f_
+        p[1] += w_
+    return out, {"how": f"measured by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of bench.py --workload {wl} "
+                        f"--frames {frames} --no-overlap, 2 x FETCH_SIZE + WRITE_SIZE per launch",
+                 "fetch_write_MB_per_launch": {k: [round(v[0] / 1e6, 2), round(v[1] / 1e6, 2)] for k, v in parts.items()}}
+
+
+def measure_in_step(wl, frames, extra_args=(), timeout=240):
+    """The kernels' durations INSIDE the step (VERDICT r5: the solo HIP-event times describe each kernel alone on the chip;
+    in the step several streams run together, every kernel takes longer and the sum of the solo times exceeds the step):
+    one child run of this script under `rocprofv3 --kernel-trace --stats` on ``frames`` frames with the streams
+    overlapped as in the timed region.  Returns ({family: {"avg_ms", "calls", "total_ms"}}, note) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    d = tempfile.mkdtemp(prefix="prc_kt_", dir="/tmp")
+    try:
+        steps, warmup = 3, 1
+        cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "kt", "--"] + \
+            _child_cmd(wl, frames, steps, warmup, extra_args)
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+        files = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, f"rocprofv3 --kernel-trace child failed (rc {r.returncode})"
+        child_line = None
+        for ln in r.stdout.splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                child_line = json.loads(ln)
+        fam_acc = {}
+        for row in csv.DictReader(open(files[0])):
+            fam, k = _kernel_family(row["Name"])
+            if fam:
+                a = fam_acc.setdefault(fam, {"calls": 0, "total_ms": 0.0, "kernels": {}})
+                calls, tot = int(row["Calls"]), float(row["TotalDurationNs"]) / 1e6
+                a["kernels"][k] = {"calls": calls, "avg_ms": tot / max(calls, 1)}
+                a["total_ms"] += tot
+                a["calls"] += calls
+        for a in fam_acc.values():
+            a["avg_ms"] = a["total_ms"] / max(a["calls"], 1)
+        return fam_acc, {"how": f"rocprofv3 --kernel-trace --stats child pass of bench.py --workload {wl} --frames {frames} --steps {steps} "
+                                f"--warmup {warmup} (streams overlapped as in the timed region; a traced run clocks 2-5 % lower)",
+                         "child_steps": steps + warmup, "child_frames": frames,
+                         "child_ms_per_step": child_line["ms_per_step"] if child_line else None}
+    except Exception as e:                                           # noqa: BLE001
+        return None, f"--kernel-trace pass: {e!r}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def secondary_leg(wl, steps=3, warmup=1, timeout=420):
+    """A short run of another BASELINE configuration in a child process (own HIP context, own buffers), so that the driver's
+    one invocation also times configs 3 and 5.  Returns the child's line reduced to what matters."""
+    import subprocess
+    t0 = time.perf_counter()
+    try:
+        cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--workload", wl, "--steps", str(steps), "--warmup", str(warmup),
+               "--no-cpu", "--traffic", "file", "--secondary", "none", "--in-step", "none"]
+        r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=timeout)
+        line = None
+        for ln in r.stdout.splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                line = json.loads(ln)
+        if r.returncode != 0 or line is None:
+            return {"error": f"child rc {r.returncode}", "stderr_tail": r.stderr[-400:]}
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "data", "roofline",
+                "hbm_moved_GBps", "hbm_frac_of_peak", "caf_only_frames_per_s_per_gpu", "caf_channels_per_launch")
+        out = {k: line[k] for k in keep if k in line}
+        out["workload"] = line["config"]["workload"]
+        out["kernels"] = line.get("kernels")
+        out["wall_seconds_incl_synthesis"] = time.perf_counter() - t0
+        return out
+    except Exception as e:                                           # noqa: BLE001 -- a side leg must never take the line down
+        return {"error": repr(e)}
 
 
 def fm_suppression(L=64):
@@ -616,6 +813,38 @@ def prconfig_main(args):
     print(json.dumps(result), flush=True)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (RANK / WORLD_SIZE unset): start the N ranks here --
+    re-exec under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 -- so that the line can never
+    claim fewer GPUs than were asked for (it used to benchmark ONE GPU and print n_gpus 1).  Fails loudly when
+    the host exposes fewer than N GPUs, or when a launcher's WORLD_SIZE disagrees with --gpus."""
+    if args.gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {args.gpus}: at least one GPU")
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if launched:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        return
+    if args.gpus == 1:
+        return
+    if args.workload == "prconfig":
+        raise SystemExit("bench.py: --workload prconfig runs on one GPU (a recording is one stream; N GPUs = N recordings)")
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, this host exposes {have} GPU(s): refusing to run a "
+                         f"{args.gpus}-GPU benchmark on fewer (no line printed)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -645,8 +874,9 @@ def main():
                          "round 5: 3690 against 3703 frames/s -- no idle share to recover)")
     ap.add_argument("--no-multi", action="store_true",
                     help="cfg5: one fast_xambg pass per illuminator instead of the shared-surveillance multi call")
-    ap.add_argument("--cpu-workers", default="32",
-                    help="worker processes of the all-cores cpu_baseline leg: a number or 'all' (every host core)")
+    ap.add_argument("--cpu-workers", default="all",
+                    help="worker processes of the all-cores cpu_baseline leg: 'all' (default: every usable host core, capped only "
+                         "by host memory) or a number")
     ap.add_argument("--cpu-asis", action="store_true",
                     help="also time the reference CAF as it ships (SciPy's per-lag np.roots call left in) on a few lag "
                          "columns, scaled: the transparency figure of SURVEY 8d")
@@ -657,18 +887,43 @@ def main():
     ap.add_argument("--traffic", default="auto", choices=["auto", "measure", "file", "none"],
                     help="roofline.traffic: measure = two rocprofv3 --pmc child passes of this script (FETCH_SIZE, WRITE_SIZE) on "
                          "one launch's worth of frames; file = the per-unit figures of profiles/traffic_latest.json (an earlier "
-                         "run); auto = measure on one GPU when the CPU leg runs too (the default line), else file; none")
+                         "run); auto = measure on one GPU when the CPU leg runs too (the default line; falls back to file, then to "
+                         "the analytic bytes, when rocprofv3 is missing or a pass fails), else file; none")
+    ap.add_argument("--in-step", default="auto", choices=["auto", "measure", "none"],
+                    help="kernels{}.in_step_ms_per_launch: one rocprofv3 --kernel-trace --stats child pass of this script with the "
+                         "streams overlapped as in the timed region; auto = on one GPU when the CPU leg runs too (the default line)")
+    ap.add_argument("--secondary", default="auto", choices=["auto", "cfg3,cfg5", "cfg3", "cfg5", "none"],
+                    help="short legs of BASELINE configs 3 and 5 in child processes, reported under `secondary`; auto = both, on the "
+                         "default single-GPU cfg2 line only")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="skip the per-kernel HIP-event section (the counter / trace child passes: every library launch they see "
+                         "then belongs to a step)")
     ap.add_argument("--markers", action="store_true",
                     help="PRC_OPT_MARKERS: the library's entry points open roctx ranges (rocprofv3 --marker-trace)")
     ap.add_argument("--dump", default=None, metavar="NPZ",
                     help="single GPU: save the maps of the last timed step's first, second, middle and last frame "
                          "(+ every frame's sum) so a test can hold the benchmarked path against an independent pass")
     args = ap.parse_args()
+    self_launch(args)
     if args.markers:
         from passiveradar_amd import _lib as _l
         _l.set_option(_l.OPT_MARKERS, 1)
     if args.workload == "prconfig":
         return prconfig_main(args)
+
+    # BASELINE configs 3 and 5, a few steps each, in child processes BEFORE this process touches the GPU (each leg has the
+    # whole 288 GB to itself; config 3 keeps 180 GB resident): the driver's one default invocation then carries driver-timed
+    # numbers for them too
+    secondary = None
+    sec = args.secondary
+    if sec == "auto":
+        sec = "cfg3,cfg5" if (args.workload == "cfg2" and args.gpus == 1 and not args.no_cpu and not args.no_clutter
+                              and args.frames is None and "RANK" not in os.environ) else "none"
+    if sec != "none":
+        secondary = {}
+        for leg in sec.split(","):
+            print(f"[bench] secondary leg {leg} ...", file=sys.stderr, flush=True)
+            secondary[leg] = secondary_leg(leg)
 
     import torch
     import torch.distributed as dist
@@ -677,8 +932,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:                                    # self_launch() has already refused every way to get here
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) are running")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -967,7 +1222,11 @@ def main():
 
     # ---- per-kernel timing with HIP events on the launch stream (rank 0) --------------------
     result = None
-    if rank == 0:
+    if rank == 0 and args.no_kernel_timing:
+        result = {"metric": f"CAF frames/sec ({wl}; child pass of a counter / trace collection)", "value": value, "unit": "frames/s",
+                  "n_gpus": world, "steps": steps, "warmup": max(args.warmup, 1), "ms_per_step": dt / steps * 1e3,
+                  "config": {"workload": wl, "frames_per_gpu_per_step": nframes}}
+    elif rank == 0:
         reps = 5
         nb = min(batch, nframes)
         ev = lambda: torch.cuda.Event(enable_timing=True)
@@ -1034,48 +1293,76 @@ def main():
                           "streams": nlocal, "samples_per_s_per_stream": (C - T) / (a.elapsed_time(b) * 1e-3)}
         dom = max(kt, key=lambda k_: kt[k_]["ms"] * kt[k_]["launches_per_step"])
         d = kt[dom]
+        # units (hop chunks for the LS kernels, frames for the CAF kernels) behind one launch of each family in this run
+        units_of = {k_: (min(nlocal, be.sub) if k_.startswith("ls_") else (nlocal if k_ == "nlms" else nb)) for k_ in kt}
+        # units of each family per frame of the step: an LS chunk per frame, x bins for the per-bin kernels
+        per_frame_units = {k_: (kt[k_]["launches_per_step"] * units_of[k_] / max(nframes, 1)) for k_ in kt}
+        default_line = world == 1 and not args.no_cpu and nill == 1
+        # ---- HBM bytes MOVED, per launch of every family: this run's own counter passes, else the committed per-unit figures
+        traffic_by, tsrc, moved_per_frame = {}, None, None
+        mode = args.traffic
+        if mode == "auto":
+            mode = "measure" if default_line else "file"
+        if mode == "measure":
+            extra = ["--sub-batch", str(args.sub_batch)] + (["--no-clutter"] if args.no_clutter else [])
+            got, note = measure_traffic(wl, units_of[dom], extra)
+            if got is None:
+                tsrc = {"how": f"not measured ({note}); "}
+                mode = "file"
+            else:
+                moved_per_frame = got.pop("_per_frame_total")
+                traffic_by, tsrc = got, note
+        tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
+        if mode == "file" and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                per_unit = tj.get("cfg2" if wl == "cfg4" else wl, {})
+                # the file holds bytes per chunk / frame; an LS launch covers one LS sub-batch, a CAF launch nb frames
+                traffic_by = {k_: per_unit[k_] * units_of[k_] for k_ in kt if k_ in per_unit}
+                if traffic_by:
+                    tsrc = {"how": ((tsrc or {}).get("how", "") + tj.get("_source", "profiles/traffic_latest.json (rocprofv3 --pmc "
+                                    "FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; not measured by this run)"))}
+                    if all(k_ in per_unit for k_ in kt if kt[k_]["bound"] != "valu"):
+                        moved_per_frame = sum(per_unit[k_] * per_frame_units[k_] for k_ in kt if k_ in per_unit)
+            except Exception:                                     # noqa: BLE001
+                traffic_by = {}
+        # ---- the kernels' durations inside the overlapped step (one kernel-trace child pass)
+        in_step, in_step_note = None, None
+        if args.in_step == "measure" or (args.in_step == "auto" and default_line):
+            extra = ["--sub-batch", str(args.sub_batch)] + (["--no-clutter"] if args.no_clutter else [])
+            in_step, in_step_note = measure_in_step(wl, min(nframes, 10 * batch), extra)
         if d["bound"] == "valu":
             achieved = d["work"] / (d["ms"] * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "valu", "achieved": achieved, "peak": VALU_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / VALU_PEAK_TFLOPS, "traffic": None,
+                    "frac_basis": "algorithmic flops (SURVEY 8d: ~20 T per step and stream) over the solo HIP-event launch time",
                     "note": "sample-recursive NLMS: one wavefront per stream, VALU-issue-bound; "
                             f"{d['samples_per_s_per_stream']:.3g} samples/s/stream x {d['streams']} streams"}
         else:
-            achieved = d["work"] / (d["ms"] * 1e-3) / 1e9
-            traffic, tsrc = None, None
-            units = min(nlocal, be.sub) if dom.startswith("ls_") else nb     # hop chunks (frames) behind one launch of `dom`
-            mode = args.traffic
-            if mode == "auto":
-                mode = "measure" if (world == 1 and not args.no_cpu and nill == 1) else "file"
-            if mode == "measure":
-                extra = ["--sub-batch", str(args.sub_batch)] + (["--no-clutter"] if args.no_clutter else [])
-                traffic, tsrc = measure_traffic(wl, dom, units, extra)
-                if traffic is None:
-                    tsrc = f"not measured ({tsrc}); "
-                    mode = "file"
-            tpath = os.path.join(REPO, "profiles", "traffic_latest.json")
-            if mode == "file" and os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    traffic = tj.get("cfg2" if wl == "cfg4" else wl, {}).get(dom)
-                    if traffic is not None:
-                        # the file holds bytes per chunk / frame; an LS launch covers one LS sub-batch, a CAF launch nb frames
-                        traffic = traffic * units
-                        tsrc = (tsrc or "") + tj.get("_source", "profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
-                                                                "earlier run of this command; not measured by this run)")
-                except Exception:
-                    traffic = None
-            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc}
+            # `frac` is the kernel's rate on the bytes it MOVED (PMC), not on SURVEY 8d's two-pass accounting, which
+            # credits the fused kernel with a separate correlation pass it never makes (kept below, labelled)
+            two_pass = d["work"] / (d["ms"] * 1e-3) / 1e9
+            traffic = traffic_by.get(dom)
             if traffic:
-                # the figure to improve: the kernel's rate on the bytes the counters saw
-                roof["achieved_measured_traffic"] = traffic / (d["ms"] * 1e-3) / 1e9
-                roof["frac_measured_traffic"] = roof["achieved_measured_traffic"] / HBM_PEAK_GBS
+                achieved, basis = traffic / (d["ms"] * 1e-3) / 1e9, "HBM bytes moved per launch (2 x FETCH_SIZE + WRITE_SIZE) over the solo HIP-event launch time"
+            elif "compulsory_work" in d:
+                achieved, basis = d["compulsory_work"] / (d["ms"] * 1e-3) / 1e9, "bytes the fused form has to move (analytic; no counters available) over the solo HIP-event launch time"
+            else:
+                achieved, basis = two_pass, "algorithmic bytes of SURVEY 8d (no counters available) over the solo HIP-event launch time"
+            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "frac_basis": basis,
+                    "traffic_source": tsrc, "frac_of_copy_ceiling": achieved / 6290.0,
+                    "solo_ms_per_launch": d["ms"], "units_per_launch": units_of[dom],
+                    # SURVEY 8d's accounting (separate correlation and FIR passes): bytes a fused kernel is credited with but
+                    # does not move -- a figure of merit of the FORMULATION, not a rate of the memory system
+                    "achieved_two_pass_accounting": two_pass, "frac_two_pass_accounting": two_pass / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": d["work"]}
             if "compulsory_work" in d:
-                # the same launch priced on the bytes the fused form cannot avoid (real traffic, PMC: the same to 2 %)
-                roof["achieved_compulsory_bytes"] = d["compulsory_work"] / (d["ms"] * 1e-3) / 1e9
-                roof["frac_compulsory_bytes"] = roof["achieved_compulsory_bytes"] / HBM_PEAK_GBS
-                roof["frac_compulsory_bytes_of_copy_ceiling"] = roof["achieved_compulsory_bytes"] / 6290.0
+                roof["compulsory_bytes_per_launch"] = d["compulsory_work"]
+                roof["frac_compulsory_bytes"] = d["compulsory_work"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if in_step and dom in in_step and traffic:
+                roof["in_step_ms_per_launch"] = in_step[dom]["avg_ms"]
+                roof["frac_in_step"] = traffic / (in_step[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         caf_bytes = 20.0 * n + 8.0 * F * (R + 1)
         if nill > 1:                                            # srv and the window are shared by the illuminators
             per_frame_bytes = nill * 8.0 * n + 8.0 * n + 4.0 * n + nill * 8.0 * F * (R + 1)
@@ -1117,23 +1404,52 @@ def main():
             # every rank, all-gathered) and the bytes of maps every rank handed to the gather per step
             "rccl_nranks": rccl_nranks, "rccl_ranks_seen": rccl_seen, "gathered_bytes_per_rank_per_step": gathered_bytes,
             "rank_ms_per_step": [t / steps * 1e3 for t in rank_seconds],
-            "hbm_algorithmic_GBps": per_frame_bytes * value / world / 1e9,
-            "hbm_frac_of_peak": per_frame_bytes * value / world / 1e9 / HBM_PEAK_GBS,
-            "hbm_frac_of_copy_ceiling": per_frame_bytes * value / world / 1e9 / 6290.0,   # MI355X_MICROARCH.md: ~6.3 TB/s achievable
+            # the whole step against the memory system, on the bytes MOVED per frame (counters: this run's passes or the
+            # committed per-unit figures); SURVEY 8d's algorithmic accounting (two passes per Doppler bin; more bytes than the
+            # fused chain moves, so its "fraction" can exceed what the chip can copy) is kept under its own name
+            "hbm_moved_bytes_per_frame": moved_per_frame,
+            "hbm_moved_GBps": (moved_per_frame * value / world / 1e9) if moved_per_frame else None,
+            "hbm_frac_of_peak": (moved_per_frame * value / world / 1e9 / HBM_PEAK_GBS) if moved_per_frame else None,
+            "hbm_frac_of_copy_ceiling": (moved_per_frame * value / world / 1e9 / 6290.0) if moved_per_frame else None,   # MI355X_MICROARCH.md: ~6.3 TB/s achievable
+            "hbm_two_pass_accounting": {"bytes_per_frame": per_frame_bytes, "GBps": per_frame_bytes * value / world / 1e9,
+                                        "frac_of_peak": per_frame_bytes * value / world / 1e9 / HBM_PEAK_GBS,
+                                        "note": "SURVEY 8d algorithmic bytes (20N + 8F(R+1) + 200C): an accounting of the unfused "
+                                                "formulation, not bytes that crossed the memory interface"},
             # caf_* timings are of ONE channel's launch; a multi-illuminator step runs all its channels in one launch per stage
             "caf_channels_per_launch": len(refs) if multi else 1,
+            # avg_ms_per_launch: HIP events around the kernel ALONE on its stream (the sum over a step of these exceeds
+            # ms_per_step: in the step three LS chains and the CAF stream run together); in_step_ms_per_launch: the same kernel's
+            # average duration in the overlapped step (kernel trace), where it shares the chip
             "kernels": {k_: {"avg_ms_per_launch": v["ms"], "launches_per_step": v["launches_per_step"], "bound": v["bound"],
+                             "units_per_launch": units_of[k_],
                              ("algorithmic_TFLOPs" if v["bound"] == "valu" else "algorithmic_GBps"):
-                                 v["work"] / (v["ms"] * 1e-3) / (1e12 if v["bound"] == "valu" else 1e9)}
+                                 v["work"] / (v["ms"] * 1e-3) / (1e12 if v["bound"] == "valu" else 1e9),
+                             "moved_bytes_per_launch": traffic_by.get(k_),
+                             "moved_GBps": (traffic_by[k_] / (v["ms"] * 1e-3) / 1e9) if traffic_by.get(k_) else None,
+                             "in_step_ms_per_launch": in_step[k_]["avg_ms"] if (in_step and k_ in in_step) else None}
                         for k_, v in kt.items()},
             "roofline": roof,
         }
+        solo_sum = sum(v["ms"] * v["launches_per_step"] for v in kt.values())
+        result["kernel_time_accounting"] = {
+            "solo_sum_ms_per_step": solo_sum, "ms_per_step": dt / steps * 1e3,
+            "note": "solo = each kernel alone on the chip (HIP events on its launch stream); the step overlaps streams, so the solo "
+                    "sum may exceed ms_per_step, and in the step every kernel runs longer than solo"}
+        if in_step:
+            child_steps = in_step_note["child_steps"]
+            tot = sum(a["total_ms"] for a in in_step.values()) / child_steps
+            result["kernel_time_accounting"].update({
+                "in_step_sum_ms_per_child_step": tot, "child_ms_per_step": in_step_note["child_ms_per_step"],
+                "child_frames_per_step": in_step_note["child_frames"],
+                "in_step_mean_concurrency": (tot / in_step_note["child_ms_per_step"]) if in_step_note["child_ms_per_step"] else None,
+                "how": in_step_note["how"]})
+        elif in_step_note:
+            result["kernel_time_accounting"]["in_step"] = f"not measured ({in_step_note})"
         caf_ms = kt["caf_segments"]["ms"] + kt["caf_doppler"]["ms"]
         result["caf_only_frames_per_s_per_gpu"] = nb / (caf_ms * 1e-3)
         result["caf_only_hbm_frac"] = caf_bytes * nb / (caf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if world == 1 and not args.no_cpu:
-            cb = cpu_baseline(wl, max_workers=(os.cpu_count() or 1) if args.cpu_workers == "all" else int(args.cpu_workers),
-                              asis=args.cpu_asis)
+            cb = cpu_baseline(wl, max_workers=None if args.cpu_workers == "all" else int(args.cpu_workers), asis=args.cpu_asis)
             result["cpu_baseline"] = cb
             result["speedup_vs_cpu_all_cores_measured"] = value / cb["value"]
             result["speedup_vs_cpu_1core"] = value / cb["one_core_value"]
@@ -1152,6 +1468,8 @@ def main():
                     "frames_per_s": 1.0 / per_frame,
                     "note": f"one np.roots(ones({q + 1})) timed on this box (LAPACK may use several cores), times the "
                             f"{R + 1} lag columns, plus the one-core path above"}
+    if result is not None and secondary is not None:
+        result["secondary"] = secondary
     if world > 1:
         dist.barrier()
         if comm is not None:

@@ -582,7 +582,55 @@ def test_bench_measures_its_own_traffic(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     roof = d["roofline"]
-    assert roof["kernel"] == "ls_fir_subtract" and roof["traffic_source"].startswith("measured by this run"), roof
+    assert roof["kernel"] == "ls_fir_subtract" and roof["traffic_source"]["how"].startswith("measured by this run"), roof
     per_chunk_bin = roof["traffic"] / 256.0            # an LS launch of the 300-frame step covers 256 hop chunks
     assert 26e6 < per_chunk_bin < 32e6, per_chunk_bin
-    assert 0.3 < roof["frac_measured_traffic"] < roof["frac"] < 1.2
+    # `frac` is the rate on the bytes MOVED; SURVEY 8d's two-pass accounting credits the fused kernel with
+    # bytes it never moves and is reported under its own name
+    assert abs(roof["frac"] - roof["traffic"] / (roof["solo_ms_per_launch"] * 1e-3) / 8e12) < 1e-9
+    assert 0.3 < roof["frac"] < roof["frac_two_pass_accounting"] < 1.2
+    assert roof["frac_of_copy_ceiling"] < 1.0
+    # every family's launch was counted, and the whole step's bytes per frame are the sum the kernels{} table implies
+    k = d["kernels"]
+    assert all(k[f]["moved_bytes_per_launch"] for f in ("caf_segments", "caf_doppler", "ls_correlate", "ls_fir_subtract"))
+    assert 180e6 < d["hbm_moved_bytes_per_frame"] < 230e6, d["hbm_moved_bytes_per_frame"]
+    assert d["hbm_frac_of_copy_ceiling"] < 1.0 < d["hbm_two_pass_accounting"]["bytes_per_frame"] / d["hbm_moved_bytes_per_frame"]
+
+
+def test_bench_reports_in_step_kernel_durations():
+    """the kernels{} table held solo times whose sum exceeds the step.  `--in-step measure` adds every
+    kernel's duration inside the overlapped step (one rocprofv3 --kernel-trace child pass) and the mean concurrency."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 is not on PATH")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--no-cpu", "--steps", "2", "--warmup", "1", "--frames", "1024",
+                        "--traffic", "file", "--in-step", "measure"], capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    acc = d["kernel_time_accounting"]
+    assert acc["child_frames_per_step"] == 1024 and acc["in_step_mean_concurrency"] > 1.0, acc
+    fused = d["kernels"]["ls_fir_subtract"]
+    assert fused["in_step_ms_per_launch"] > fused["avg_ms_per_launch"] * 0.95, fused   # sharing the chip never makes it faster
+    assert d["roofline"]["frac_in_step"] <= d["roofline"]["frac"] * 1.05
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus N` without a launcher used to benchmark ONE GPU and print n_gpus 1.  It now
+    starts the N ranks itself (torch.distributed.run on 127.0.0.1) -- and the line says how many RCCL saw."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "512"],
+                       capture_output=True, text=True, timeout=1500, cwd=repo, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["rccl_nranks"] == 2 and len(d["rank_ms_per_step"]) == 2, d

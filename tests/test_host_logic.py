@@ -463,3 +463,26 @@ def test_zarr_reader_and_writer_against_the_specifications_own_example(tmp_path)
     p = output.save_range_doppler_zarr(str(tmp_path / "X.zarr"), frames)
     doc = open(os.path.join(p, ".zarray"), "rb").read()
     assert doc == output.zarray_json(json.loads(doc)) and np.array_equal(output.read_zarr_v2(p), np.moveaxis(frames, 0, 2))
+
+
+def test_bench_gpus_n_refuses_to_run_on_fewer_gpus():
+    """`python bench.py --gpus N` with no launcher around it must start N ranks itself or fail loudly --
+    never benchmark one GPU and print `n_gpus: 1`.  On a box with fewer than N GPUs (this container has none): a non-zero
+    exit, the reason on stderr, no JSON line.  A launcher whose WORLD_SIZE disagrees with --gpus is refused the same way."""
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except ImportError:
+        have = 0
+    want = have + 1 if have else 2
+    r = subprocess.run([sys.executable, bench, "--gpus", str(max(want, 2))], capture_output=True, text=True, timeout=300, env=clean)
+    assert r.returncode != 0
+    assert f"--gpus {max(want, 2)} asked for, this host exposes {have} GPU(s)" in r.stderr, r.stderr[-500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(clean, RANK="0", WORLD_SIZE="1"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr, r.stderr[-500:]
