@@ -39,8 +39,9 @@ int main(void) {
     CHK(prc_device_count(&ndev));
     if (ndev < 1) { fprintf(stderr, "no ROCm device\n"); return 2; }
     prc_caf_desc d;
+    PRC_DESC_INIT(d);                                /* zeroes, then struct_size = sizeof(d), magic */
     d.n = n; d.range_bins = R; d.freq_bins = F; d.max_frames = 1; d.method = 0; d.doppler = 0; d.ntaps = 0; d.taps_host = NULL;
-    d.multi = PRC_CAF_MULTI_AUTO; d.reserved = 0;
+    d.multi = PRC_CAF_MULTI_AUTO;
     prc_caf_plan* plan = NULL;
     CHK(prc_caf_plan_create(&plan, &d));
     void *dref = NULL, *dsrv = NULL, *dout = NULL;

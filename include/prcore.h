@@ -19,18 +19,32 @@
  *     reference's error convention (range_doppler_processing.py:46-49, clutter_removal.py:28-29).
  *   - a plan may be used by one thread at a time (internally serialised by a mutex);
  *     different plans may be used concurrently from different threads (dask-style callers).
+ *   - descriptors: every descriptor struct starts with `uint32_t struct_size`, which the host sets to sizeof(the
+ *     struct) of the header IT was compiled against (ctypes: ctypes.sizeof), and `uint32_t magic` = PRC_DESC_MAGIC
+ *     (PRC_DESC_INIT(d) zeroes a descriptor and sets both).  Descriptors only ever grow at the end.  The library reads
+ *     min(struct_size, its own sizeof) bytes and takes fields the host did not know as 0 (= AUTO / default).  A wrong
+ *     magic (a host built against a pre-600 header has the first field of the old layout there), a struct_size below
+ *     the version-600 layout or not a multiple of 4 is PRC_EINVAL with a message naming the sizes -- a host built
+ *     against another layout can never make the library read past its struct.
  */
 #ifndef PRCORE_H
 #define PRCORE_H
 
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define PRC_VERSION 500   /* 500: prc_frequency_shift_phases, prc_frontend_execute2, prc_cfar2d_c64, prc_mem_info, PRC_OPT_MARKERS; 401: prc_comm_loopback, PRC_OPT_FE_METHOD, PRC_OPT_CFAR_METHOD; 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
+#define PRC_DESC_MAGIC 0x36435250u     /* "PRC6" */
+/* zero a descriptor and fill in its header; then set the fields */
+#define PRC_DESC_INIT(d) do { memset(&(d), 0, sizeof(d)); (d).struct_size = (uint32_t)sizeof(d); (d).magic = PRC_DESC_MAGIC; } while (0)
+
+#define PRC_VERSION 600   /* 600: every descriptor (prc_caf_desc, prc_ls_desc, prc_frontend_desc, prc_iir_desc) starts with `struct_size`
+                             (layout break: rebuild hosts; from here on descriptors only grow at the end and an older host keeps working);
+                             500: prc_frequency_shift_phases, prc_frontend_execute2, prc_cfar2d_c64, prc_mem_info, PRC_OPT_MARKERS; 401: prc_comm_loopback, PRC_OPT_FE_METHOD, PRC_OPT_CFAR_METHOD; 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
                              prc_comm_count; 310: prc_ls_desc.method = 4, NLMS up to 8192 taps */
 
 typedef enum prc_status {
@@ -127,6 +141,8 @@ typedef enum prc_caf_multi_mode {
 } prc_caf_multi_mode;
 
 typedef struct prc_caf_desc {
+    uint32_t struct_size;  /* sizeof(prc_caf_desc) as the host compiled it (see Conventions)   */
+    uint32_t magic;        /* PRC_DESC_MAGIC                                                 */
     int64_t n;             /* samples per CPI after zero padding = inputLen (:52-55)         */
     int32_t range_bins;    /* rangeBins; the surface has range_bins+1 columns (:64)          */
     int32_t freq_bins;     /* freqBins; decimation q = (int)(n / freq_bins) (:61)            */
@@ -136,8 +152,8 @@ typedef struct prc_caf_desc {
     int32_t ntaps;         /* 0: boxcar ones(q+1) (shortFilt=True, :72); else length of taps */
     const float* taps_host;/* HOST pointer, copied at plan creation (shortFilt=False, :76)   */
     int32_t multi;         /* prc_caf_multi_mode of prc_caf_execute_multi (0 = AUTO)         */
-    int32_t reserved;      /* 0                                                              */
 } prc_caf_desc;
+#define PRC_CAF_DESC_SIZE_600 56u      /* sizeof(prc_caf_desc) at PRC_VERSION 600: the smallest struct_size accepted */
 
 typedef struct prc_caf_plan prc_caf_plan;
 
@@ -178,6 +194,8 @@ int prc_caf_execute_doppler(prc_caf_plan* plan, void* out, int32_t nframes, void
 
 /* ---- block least-squares clutter cancellers (clutter_removal.py) ------------------- */
 typedef struct prc_ls_desc {
+    uint32_t struct_size;  /* sizeof(prc_ls_desc) as the host compiled it (see Conventions)     */
+    uint32_t magic;        /* PRC_DESC_MAGIC                                                 */
     int64_t n;             /* samples per block (chunk)                                     */
     int32_t filter_len;    /* filterLen                                                     */
     int32_t peek;          /* non-causal taps (default 10 in the reference)                 */
@@ -198,6 +216,7 @@ typedef struct prc_ls_desc {
                               its three complex128 T-vectors in LDS up to 3413 taps, the autocorrelation in a
                               global workspace up to 5120, all three there beyond (seconds at 10^4 taps)       */
 } prc_ls_desc;
+#define PRC_LS_DESC_SIZE_600 40u
 
 typedef struct prc_ls_plan prc_ls_plan;
 
@@ -251,6 +270,8 @@ typedef enum prc_raw_dtype {
 } prc_raw_dtype;
 
 typedef struct prc_frontend_desc {
+    uint32_t struct_size;  /* sizeof(prc_frontend_desc) as the host compiled it (see Conventions)      */
+    uint32_t magic;        /* PRC_DESC_MAGIC                                                     */
     int64_t n_in;          /* complex samples per block (= raw scalars / 2)                     */
     int32_t raw_dtype;     /* prc_raw_dtype of the input                                         */
     int32_t up, down;      /* rational resampling factor, already reduced by their gcd           */
@@ -260,6 +281,7 @@ typedef struct prc_frontend_desc {
     const float* taps_host;/* HOST: firwin(20 max+1, 1/max, ('kaiser',5.0)) * up with n_pre_pad
                               leading zeros (scipy.signal.resample_poly's h), copied at creation  */
 } prc_frontend_desc;
+#define PRC_FRONTEND_DESC_SIZE_600 48u
 
 typedef struct prc_frontend_plan prc_frontend_plan;
 int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_frontend_desc* desc);
@@ -309,6 +331,8 @@ int prc_cfar2d_c64(const void* X, int32_t H, int32_t W, int32_t fw, int32_t gw, 
  * (zeros/poles/gain of the digital low-pass) and says how many samples its impulse response needs to
  * settle (`settle`, >= log(1e-9)/log(max|pole|)). */
 typedef struct prc_iir_desc {
+    uint32_t struct_size;  /* sizeof(prc_iir_desc) as the host compiled it (see Conventions)           */
+    uint32_t magic;        /* PRC_DESC_MAGIC                                                      */
     int32_t q;             /* keep every q-th filtered sample                                    */
     int32_t padlen;        /* sosfiltfilt's odd-extension length, 3*(2*nsections+1 - ...) = 27    */
     int32_t settle;        /* constant-extension length standing in for the steady-state zi      */
@@ -317,6 +341,7 @@ typedef struct prc_iir_desc {
     const double* poles_host;  /* HOST (re, im) pairs                                             */
     double gain;
 } prc_iir_desc;
+#define PRC_IIR_DESC_SIZE_600 56u
 /* y[j] = filtfilt(x)[j*q], j < ceil(n/q); x, y complex64 DEVICE.  PRC_ESHAPE if n <= padlen. */
 int prc_decimate_iir(const void* x, int64_t n, const prc_iir_desc* iir, void* y, void* stream);
 /* find_channel_offset(s1, s2, nd, nl), signal_utils.py:73-78: B1 = decimate(s1, nd), B2 = decimate(s2, nd)

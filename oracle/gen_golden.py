@@ -575,6 +575,19 @@ def ls_wide_cases():
     save("ls_direct_t1034", seed=scene.scene_seed(32), N=n2, L=L, fs=1.0e7, reg=1.0, out=o2, taps=t2)
 
 
+def direct_xambg_case():
+    """Round 6: range_doppler_processing.py:93-124 (never on the reference's processing path; the drop-in exists so that an
+    import swap does not raise).  Two shapes: an echo at a known (Doppler, delay) cell on a power-of-two CPI, and an odd
+    length with a non-integer Doppler step."""
+    print("direct_xambg")
+    out = {}
+    for tag, n, R, F, fs, i in (("a", 4096, 20, 64, 4096.0, 0), ("b", 3001, 9, 16, 8000.0, 1)):
+        a, s = scene.make_scene(n, fs, R, scene.scene_seed(96, i), targets=((7, 5.0 * fs / n, 0.5),))
+        out.update({f"ref_{tag}": a, f"srv_{tag}": s, f"R_{tag}": R, f"F_{tag}": F, f"fs_{tag}": fs,
+                    f"out_{tag}": ref_rd.direct_xambg(a, s, R, F, fs)})
+    save("direct_xambg", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also generate the cfg1/2/3 CAF goldens (minutes)")
@@ -600,6 +613,7 @@ if __name__ == "__main__":
         offset_case()
         ls_cfg1_case()
         ls_wide_cases()
+        direct_xambg_case()
     if args.big or args.only_big:
         big_cases()
         pipeline_cfg1_case()

@@ -34,29 +34,47 @@ class PrcoreError(RuntimeError):
         self.code = code
 
 
-class CafDesc(C.Structure):
-    _fields_ = [("n", C.c_int64), ("range_bins", C.c_int32), ("freq_bins", C.c_int32),
+DESC_MAGIC = 0x36435250      # PRC_DESC_MAGIC, "PRC6"
+
+
+class _Desc(C.Structure):
+    """Descriptor structs of include/prcore.h: the first field says how large the HOST's struct is (version 600), so the
+    library never reads past it and takes fields the host does not know as 0."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(type(self))
+        self.magic = DESC_MAGIC
+
+
+class CafDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("magic", C.c_uint32),
+                ("n", C.c_int64), ("range_bins", C.c_int32), ("freq_bins", C.c_int32),
                 ("max_frames", C.c_int32), ("method", C.c_int32), ("doppler", C.c_int32),
-                ("ntaps", C.c_int32), ("taps_host", C.POINTER(C.c_float)), ("multi", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("ntaps", C.c_int32), ("taps_host", C.POINTER(C.c_float)), ("multi", C.c_int32)]
 
 
-class LsDesc(C.Structure):
-    _fields_ = [("n", C.c_int64), ("filter_len", C.c_int32), ("peek", C.c_int32),
+class LsDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("magic", C.c_uint32),
+                ("n", C.c_int64), ("filter_len", C.c_int32), ("peek", C.c_int32),
                 ("circular", C.c_int32), ("max_blocks", C.c_int32), ("method", C.c_int32)]
 
 
-class FrontendDesc(C.Structure):
-    _fields_ = [("n_in", C.c_int64), ("raw_dtype", C.c_int32), ("up", C.c_int32), ("down", C.c_int32),
+class FrontendDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("magic", C.c_uint32),
+                ("n_in", C.c_int64), ("raw_dtype", C.c_int32), ("up", C.c_int32), ("down", C.c_int32),
                 ("ntaps", C.c_int32), ("n_pre_remove", C.c_int32), ("max_blocks", C.c_int32),
                 ("taps_host", C.POINTER(C.c_float))]
 
 
-class IirDesc(C.Structure):
-    _fields_ = [("q", C.c_int32), ("padlen", C.c_int32), ("settle", C.c_int32), ("nzeros", C.c_int32),
+class IirDesc(_Desc):
+    _fields_ = [("struct_size", C.c_uint32), ("magic", C.c_uint32),
+                ("q", C.c_int32), ("padlen", C.c_int32), ("settle", C.c_int32), ("nzeros", C.c_int32),
                 ("npoles", C.c_int32), ("zeros_host", C.POINTER(C.c_double)),
                 ("poles_host", C.POINTER(C.c_double)), ("gain", C.c_double)]
 
+
+MIN_LIB_VERSION = 600      # PRC_VERSION of include/prcore.h these ctypes declarations mirror
 
 RAW_DTYPES = {"int8": 0, "uint8": 1, "int16": 2, "float32": 3, "complex64": 4}
 
@@ -175,6 +193,14 @@ def lib():
                     "passiveradar_amd has no CPU fallback.")
             _share_hip_runtime_with_torch()
             handle = C.CDLL(LIB_PATH)
+            # a stale build next to newer Python would fail below with an AttributeError on the first missing symbol, or --
+            # worse -- read descriptors of another layout: say what to do instead
+            handle.prc_version.restype = C.c_int
+            built = handle.prc_version()
+            if built < MIN_LIB_VERSION:
+                raise ImportError(f"{LIB_PATH} was built from prcore.h version {built}, this package needs >= "
+                                  f"{MIN_LIB_VERSION} (descriptor layout with struct_size): rebuild it with "
+                                  f"`make -C passiveradar_amd/csrc`")
             for name, (res, args) in _SIGNATURES.items():
                 fn = getattr(handle, name)
                 fn.restype = res

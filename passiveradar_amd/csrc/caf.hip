@@ -100,8 +100,12 @@ static int pick_group(const prc_caf_desc* d) {
     return g;
 }
 
-extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
-    PRC_REQUIRE(plan && d, PRC_EINVAL, "prc_caf_plan_create: null argument");
+extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* host_desc) {
+    PRC_REQUIRE(plan && host_desc, PRC_EINVAL, "prc_caf_plan_create: null argument");
+    static_assert(sizeof(prc_caf_desc) == PRC_CAF_DESC_SIZE_600, "prc_caf_desc grew: keep PRC_CAF_DESC_SIZE_600, default the new fields to 0");
+    prc_caf_desc mine;
+    if (int rc = prc_take_desc(&mine, host_desc, PRC_CAF_DESC_SIZE_600, "prc_caf_plan_create", "prc_caf_desc")) return rc;
+    const prc_caf_desc* d = &mine;
     PRC_REQUIRE(d->n > 0 && d->range_bins >= 0 && d->freq_bins > 0 && d->max_frames > 0,
                 PRC_EINVAL, "prc_caf_plan_create: non-positive size");
     PRC_REQUIRE(d->freq_bins <= d->n, PRC_EINVAL,
@@ -109,11 +113,9 @@ extern "C" int prc_caf_plan_create(prc_caf_plan** plan, const prc_caf_desc* d) {
                 "divides by q = int(n/freq_bins) = 0", d->freq_bins, (long long)d->n);
     PRC_REQUIRE(d->range_bins < d->n, PRC_EINVAL, "prc_caf_plan_create: range_bins >= n");
     PRC_REQUIRE(d->ntaps == 0 || d->taps_host, PRC_EINVAL, "prc_caf_plan_create: ntaps without taps");
-    // every argument check comes before the plan exists (a failed check after `new` leaked it); `reserved`
-    // must be 0, which also catches a host compiled against the shorter descriptor of header version 310
+    // every argument check comes before the plan exists (a failed check after `new` leaked it)
     PRC_REQUIRE(d->multi >= PRC_CAF_MULTI_AUTO && d->multi <= PRC_CAF_MULTI_PAIRS, PRC_EINVAL,
                 "prc_caf_plan_create: unknown multi mode %d", d->multi);
-    PRC_REQUIRE(d->reserved == 0, PRC_EINVAL, "prc_caf_plan_create: prc_caf_desc.reserved must be 0 (got %d)", d->reserved);
     prc_caf_plan* p = new prc_caf_plan();
     p->desc = *d;
     p->desc.taps_host = nullptr;

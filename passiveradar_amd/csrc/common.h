@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <string.h>
 #include <mutex>
 #include "../../include/prcore.h"
 
@@ -40,6 +41,32 @@ void prc_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Descriptor hand-over (prcore.h, Conventions): the host says how large ITS struct is in the first field; copy what both
+// sides know into a zeroed struct of OUR layout, never read past the host's struct, refuse sizes below the version-600
+// layout.  `mine` is what the rest of the library reads.
+template <class D>
+static inline int prc_take_desc(D* mine, const D* theirs, uint32_t min_size, const char* who, const char* what) {
+    uint32_t sz, magic;
+    memcpy(&sz, theirs, sizeof(sz));                    // the two fields every layout from 600 on has, at offsets 0 and 4
+    memcpy(&magic, (const char*)theirs + 4, sizeof(magic));
+    if (magic != PRC_DESC_MAGIC) {
+        prc_set_error("%s: %s.magic = 0x%08x, not PRC_DESC_MAGIC (0x%08x): the host was built against a prcore.h older than "
+                      "version 600 (descriptors now start with struct_size, magic -- PRC_DESC_INIT) and must be rebuilt",
+                      who, what, magic, PRC_DESC_MAGIC);
+        return PRC_EINVAL;
+    }
+    if (sz < min_size || (sz & 3u) || sz > (1u << 16)) {
+        prc_set_error("%s: %s.struct_size = %u, expected %u (this library, header version %d) or at least %u (version 600): "
+                      "set it to sizeof(%s) of the prcore.h the host was built against -- a host built against a pre-600 "
+                      "header must be rebuilt", who, what, sz, (unsigned)sizeof(D), PRC_VERSION, min_size, what);
+        return PRC_EINVAL;
+    }
+    memset(mine, 0, sizeof(D));
+    memcpy(mine, theirs, sz < sizeof(D) ? sz : sizeof(D));
+    mine->struct_size = (uint32_t)sizeof(D);
+    return PRC_OK;
+}
 
 // hipFuncAttributeMaxDynamicSharedMemorySize for a kernel that wants more than 64 KB of LDS: set once per (kernel, device),
 // not on every launch (util.hip)

@@ -536,8 +536,12 @@ extern "C" int prc_frontend_plan_destroy(prc_frontend_plan* p) {
     return PRC_OK;
 }
 
-extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_frontend_desc* d) {
-    PRC_REQUIRE(plan && d, PRC_EINVAL, "prc_frontend_plan_create: null argument");
+extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_frontend_desc* host_desc) {
+    PRC_REQUIRE(plan && host_desc, PRC_EINVAL, "prc_frontend_plan_create: null argument");
+    static_assert(sizeof(prc_frontend_desc) == PRC_FRONTEND_DESC_SIZE_600, "prc_frontend_desc grew: keep PRC_FRONTEND_DESC_SIZE_600, default the new fields to 0");
+    prc_frontend_desc mine;
+    if (int rc = prc_take_desc(&mine, host_desc, PRC_FRONTEND_DESC_SIZE_600, "prc_frontend_plan_create", "prc_frontend_desc")) return rc;
+    const prc_frontend_desc* d = &mine;
     PRC_REQUIRE(d->n_in > 1 && d->n_in < ((int64_t)1 << 30) && d->up > 0 && d->down > 0 && d->ntaps > 0 && d->taps_host &&
                 d->max_blocks > 0, PRC_EINVAL, "prc_frontend_plan_create: bad size (blocks of 2 .. 2^30 complex samples)");
     PRC_REQUIRE(d->raw_dtype >= PRC_RAW_I8 && d->raw_dtype <= PRC_RAW_C64, PRC_EINVAL,

@@ -18,7 +18,30 @@
 // function pointers below are declared as decltype(&ncclXxx), so a change of any signature, of ncclFloat32 or of the id's
 // size in the installed RCCL is a compile error here, not a silent mismatch at the first multi-GPU run.  Nothing is
 // linked: the header only declares, the symbols are still looked up in the library the process already carries.
+// A ROCm install without RCCL's development header still builds the (single-GPU) library: the declarations RCCL 2.x has
+// kept stable are restated below, checked against nothing at compile time -- prc_comm_rccl_version says what was bound.
+#if __has_include(<rccl/rccl.h>) && !defined(PRC_NO_RCCL_HEADER)      /* the define: a build test of the branch below */
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6,
+               ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId* uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+const char* ncclGetErrorString(ncclResult_t result);
+ncclResult_t ncclGetVersion(int* version);
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count);
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int* rank);
+}
+#endif
 
 namespace {
 

@@ -1053,8 +1053,12 @@ static int ls_plan_create_impl(prc_ls_plan** plan, const prc_ls_desc* d, bool al
     return PRC_OK;
 }
 
-extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* d) {
-    return ls_plan_create_impl(plan, d, true);
+extern "C" int prc_ls_plan_create(prc_ls_plan** plan, const prc_ls_desc* host_desc) {
+    PRC_REQUIRE(plan && host_desc, PRC_EINVAL, "prc_ls_plan_create: null argument");
+    static_assert(sizeof(prc_ls_desc) == PRC_LS_DESC_SIZE_600, "prc_ls_desc grew: keep PRC_LS_DESC_SIZE_600, default the new fields to 0");
+    prc_ls_desc mine;
+    if (int rc = prc_take_desc(&mine, host_desc, PRC_LS_DESC_SIZE_600, "prc_ls_plan_create", "prc_ls_desc")) return rc;
+    return ls_plan_create_impl(plan, &mine, true);
 }
 
 static PhaseRamp make_ramp(double fc, double fs, double phase_offset) {

@@ -23,6 +23,7 @@
 // sample).  The step sizes of a window come from the first wavefront's prepass.  The split is for register space only: at
 // T = 1034 a stream alone steps in 253 ns on one wavefront, 334 on two, 302 on four (tools/nlms_waves_probe.py).
 #include "common.h"
+#include <vector>
 
 struct NlmsArgs {
     const float2* ref;
@@ -367,7 +368,10 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
     PRC_REQUIRE(stride >= n && out_stride >= n, PRC_ESHAPE, "prc_nlms_execute: stride shorter than n");
     const int T = filter_len + peek;
     if (T > 8192) {
-        // the plain form for any length; its tap workspace lives for the call, so this path synchronises the stream
+        // the plain form for any length.  Its tap workspace is a grow-only block per host thread and (device, stream),
+        // kept between calls: nothing synchronises in the steady state and the call can be captured in a graph once the
+        // block exists (it used to hipMalloc / synchronise / hipFree per call).  Calls on one stream are
+        // ordered by the stream; only GROWING a block waits for that stream first (its kernels may still read the old one).
         NlmsArgs g;
         g.ref = (const float2*)ref;
         g.srv = (const float2*)srv;
@@ -383,16 +387,50 @@ extern "C" int prc_nlms_execute(const void* ref, const void* srv, int64_t n, int
         g.mu = mu;
         g.nstreams = nstreams;
         g.kt = 0;
-        float2* wbuf = nullptr;
-        PRC_HIP(hipMalloc(&wbuf, sizeof(float2) * (size_t)nstreams * T));
-        hipLaunchKernelGGL(nlms_generic_kernel, dim3(nstreams), dim3(NLG_THREADS), 0, (hipStream_t)stream, g, wbuf);
-        const hipError_t le = hipGetLastError();
-        const hipError_t se = hipStreamSynchronize((hipStream_t)stream);
-        (void)hipFree(wbuf);
-        if (le != hipSuccess || se != hipSuccess) {
-            prc_set_error("prc_nlms_execute: the any-length kernel failed: %s", hipGetErrorString(le != hipSuccess ? le : se));
-            return PRC_EHIP;
+        struct Scratch { float2* p = nullptr; size_t cap = 0; int dev = -1; hipStream_t stream = nullptr; };
+        static thread_local std::vector<Scratch> pool;
+        int dev = 0;
+        PRC_HIP(hipGetDevice(&dev));
+        const size_t need = sizeof(float2) * (size_t)nstreams * T;
+        Scratch* hit = nullptr;
+        for (Scratch& c : pool)
+            if (c.dev == dev && c.stream == (hipStream_t)stream) { hit = &c; break; }
+        if (!hit) {
+            size_t mine = 0;
+            for (const Scratch& c : pool) mine += c.dev == dev;
+            if (mine >= 8) {                                  // a host cycling through streams: start over on this device
+                PRC_HIP(hipDeviceSynchronize());
+                std::vector<Scratch> keep;
+                for (Scratch& c : pool) {
+                    if (c.dev == dev) (void)hipFree(c.p);
+                    else keep.push_back(c);
+                }
+                pool.swap(keep);
+            }
+            pool.push_back(Scratch());
+            hit = &pool.back();
+            hit->dev = dev;
+            hit->stream = (hipStream_t)stream;
         }
+        if (hit->cap < need) {
+            if (hit->p) {
+                PRC_HIP(hipStreamSynchronize((hipStream_t)stream));
+                (void)hipFree(hit->p);
+                hit->p = nullptr;
+                hit->cap = 0;
+            }
+            const hipError_t me = hipMalloc(&hit->p, need);
+            if (me != hipSuccess) {
+                (void)hipGetLastError();                      // the failed allocation must not stay behind as a sticky error
+                hit->p = nullptr;
+                prc_set_error("prc_nlms_execute: %zu bytes of tap workspace for %d streams of %d taps: %s", need, nstreams, T,
+                              hipGetErrorString(me));
+                return PRC_EHIP;
+            }
+            hit->cap = need;
+        }
+        hipLaunchKernelGGL(nlms_generic_kernel, dim3(nstreams), dim3(NLG_THREADS), 0, (hipStream_t)stream, g, hit->p);
+        PRC_LAUNCH_CHECK();
         return PRC_OK;
     }
     int nwave = T <= 2048 ? 1 : (T <= 4096 ? 2 : 4);             // wavefronts per stream

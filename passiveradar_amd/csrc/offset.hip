@@ -248,10 +248,16 @@ static int64_t filt_len(int64_t n, const prc_iir_desc* d) {
     return (int64_t)next_pow2((size_t)(n + 2 * (int64_t)d->padlen + 2 * (int64_t)d->settle));
 }
 
-extern "C" int prc_decimate_iir(const void* x, int64_t n, const prc_iir_desc* iir, void* y, void* stream) {
+extern "C" int prc_decimate_iir(const void* x, int64_t n, const prc_iir_desc* host_iir, void* y, void* stream) {
     PRC_RANGE("prc_decimate_iir");
+    PRC_REQUIRE(host_iir != nullptr, PRC_EINVAL, "iir descriptor is NULL");
+    static_assert(sizeof(prc_iir_desc) == PRC_IIR_DESC_SIZE_600, "prc_iir_desc grew: keep PRC_IIR_DESC_SIZE_600, default the new fields to 0");
+    prc_iir_desc mine;
+    int rc = prc_take_desc(&mine, host_iir, PRC_IIR_DESC_SIZE_600, "prc_decimate_iir", "prc_iir_desc");
+    if (rc) return rc;
+    const prc_iir_desc* iir = &mine;
     IirDev f;
-    int rc = check_iir(iir, &f);
+    rc = check_iir(iir, &f);
     if (rc) return rc;
     PRC_REQUIRE(x && y, PRC_EINVAL, "x / y is NULL");
     PRC_REQUIRE(n > iir->padlen, PRC_ESHAPE,
@@ -268,11 +274,17 @@ extern "C" int prc_decimate_iir(const void* x, int64_t n, const prc_iir_desc* ii
     return PRC_OK;
 }
 
-extern "C" int prc_channel_offset(const void* s1, int64_t n1, const void* s2, int64_t n2, const prc_iir_desc* iir,
+extern "C" int prc_channel_offset(const void* s1, int64_t n1, const void* s2, int64_t n2, const prc_iir_desc* host_iir,
                                   int64_t nl, float* xc_out, int64_t* n_xc, int64_t* argmax_out, void* stream) {
     PRC_RANGE("prc_channel_offset");
+    PRC_REQUIRE(host_iir != nullptr, PRC_EINVAL, "iir descriptor is NULL");
+    static_assert(sizeof(prc_iir_desc) == PRC_IIR_DESC_SIZE_600, "prc_iir_desc grew: keep PRC_IIR_DESC_SIZE_600, default the new fields to 0");
+    prc_iir_desc mine;
+    int rc = prc_take_desc(&mine, host_iir, PRC_IIR_DESC_SIZE_600, "prc_channel_offset", "prc_iir_desc");
+    if (rc) return rc;
+    const prc_iir_desc* iir = &mine;
     IirDev f;
-    int rc = check_iir(iir, &f);
+    rc = check_iir(iir, &f);
     if (rc) return rc;
     PRC_REQUIRE(s1 && s2 && argmax_out, PRC_EINVAL, "s1 / s2 / argmax_out is NULL");
     PRC_REQUIRE(nl >= 0, PRC_EINVAL, "nl must be >= 0");

@@ -54,7 +54,9 @@ static bool roctx_bind() {
     });
     return g_roctx_push != nullptr;
 }
-PrcRange::PrcRange(const char* name) : on(g_markers.load(std::memory_order_relaxed) != 0) {
+// g_markers is stored with release after roctx_bind() wrote the two function pointers and loaded with acquire here: a
+// thread that sees the flag also sees the pointers (the relaxed pair was a formal data race)
+PrcRange::PrcRange(const char* name) : on(g_markers.load(std::memory_order_acquire) != 0) {
     if (on) (void)g_roctx_push(name);
 }
 PrcRange::~PrcRange() {
@@ -102,7 +104,7 @@ extern "C" int prc_set_option(int32_t option, int64_t value) {
     }
     PRC_REQUIRE(ok, PRC_EINVAL, "prc_set_option: value %lld out of range for option %d", (long long)value, option);
     g_opt[option].store(value);
-    if (option == PRC_OPT_MARKERS) g_markers.store((int)value);
+    if (option == PRC_OPT_MARKERS) g_markers.store((int)value, std::memory_order_release);
     return PRC_OK;
 }
 extern "C" int prc_get_option(int32_t option, int64_t* value) {

@@ -39,7 +39,6 @@ class CafPlan:
         d.n, d.range_bins, d.freq_bins = self.n, self.range_bins, self.freq_bins
         d.max_frames, d.method, d.doppler = self.max_frames, int(method), int(doppler)
         d.multi = _lib.CAF_MULTI_MODES[multi] if isinstance(multi, str) else int(multi)
-        d.reserved = 0
         self._taps = None
         if taps is not None:
             self._taps = np.ascontiguousarray(taps, dtype=np.float32)

@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib, engine
 
-__all__ = ["fast_xambg", "fast_xambg_multi", "caf_plan_for", "set_default_methods"]
+__all__ = ["fast_xambg", "fast_xambg_multi", "direct_xambg", "caf_plan_for", "set_default_methods"]
 
 # Kernel selection used by fast_xambg (0 = let the plan decide).  Not part of the reference
 # signature; tests flip it to run the same cases through every kernel family.
@@ -112,6 +112,40 @@ def fast_xambg(refChannel, srvChannel, rangeBins, freqBins, inputLen=None, windo
         d_win.upload(window)
     plan.execute(d_ref, d_srv, d_out, 1, n, n_in, d_win)
     return d_out.download((int(freqBins), int(rangeBins) + 1, 1), np.complex64)
+
+
+def direct_xambg(refChannel, srvChannel, rangeBins, freqBins, sampleRate):
+    """Direct (time-domain) cross-ambiguity function, range_doppler_processing.py:93-124: for every Doppler bin i the
+    reference is shifted by (i - freqBins/2) / CPI Hz (frequency_shift, float32 phase ramp) and correlated with the
+    surveillance channel at lags 0..rangeBins (xcorr).  The reference never calls it on its processing path (SURVEY 8a:
+    an independent peak check); it is here so that swapping the import line never raises.  A thin composition of
+    prc_frequency_shift + prc_xcorr on device buffers: both channels go up once, the surface comes down once.
+
+    Returns (freqBins, rangeBins+1, 1) complex64; row i is Doppler (i - freqBins/2)/CPI (NOT mirrored like
+    fast_xambg's rows), column k is delay rangeBins - k."""
+    if tuple(refChannel.shape) != tuple(srvChannel.shape):                  # :107-108
+        raise ValueError("Input vectors must have the same length")
+    ref = np.ascontiguousarray(refChannel.cpu().numpy() if _lib.is_device_tensor(refChannel) else refChannel, dtype=np.complex64)
+    srv = np.ascontiguousarray(srvChannel.cpu().numpy() if _lib.is_device_tensor(srvChannel) else srvChannel, dtype=np.complex64)
+    if ref.ndim != 1:
+        raise ValueError("direct_xambg takes one-dimensional channels")
+    n, R, F = ref.shape[0], int(rangeBins), int(freqBins)
+    if R < 0:
+        raise ValueError("index can't contain negative values")              # np.pad inside xcorr
+    cpi = n / sampleRate                                                     # :111
+    st = engine.staging()
+    d_ref = st.get("dx_ref", 8 * n)
+    d_srv = st.get("dx_srv", 8 * n)
+    d_shift = st.get("dx_shift", 8 * n)
+    d_out = st.get("dx_out", 8 * max(F, 1) * (R + 1))
+    d_ref.upload(ref)
+    d_srv.upload(srv)
+    L = _lib.lib()
+    for i in range(F):
+        df = (i - 0.5 * F) / cpi                                             # :119
+        _lib.check(L.prc_frequency_shift(d_ref.ptr, d_shift.ptr, n, float(df), float(sampleRate), 0.0, None))
+        _lib.check(L.prc_xcorr(d_shift.ptr, d_srv.ptr, n, R, 0, d_out.ptr + 8 * i * (R + 1), None))   # :123
+    return d_out.download((F, R + 1, 1), np.complex64)
 
 
 def fast_xambg_multi(refChannels, srvChannel, rangeBins, freqBins, inputLen=None, window=None, shortFilt=True,

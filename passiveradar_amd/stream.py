@@ -609,6 +609,13 @@ class HipBackend:
             ev = torch.cuda.Event()
             ev.record(main)
             per = -(-self.batch // 2)
+            # the lane streams read and write tensors the caching allocator handed out on OTHER streams: tell it, so that a
+            # tensor freed by the caller (join=False, outs=None) is not handed out again while a lane still works on it
+            # (ADVICE r5).  With join=False the caller must still order its own reads of `outs` behind the lanes
+            # (torch.cuda.synchronize, or wait_stream on HipBackend._lane_streams).
+            for st in self._lane_streams[:min(2, -(-nframes // per))]:
+                for t in list(outs) + list(ref_pads) + [clean_pad]:
+                    t.record_stream(st)
             with torch.cuda.device(self.device):
                 for i, f0 in enumerate(range(0, nframes, per)):
                     st, plan = self._lane_streams[i & 1], self._lane_plans[i & 1]

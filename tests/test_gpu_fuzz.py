@@ -1,0 +1,39 @@
+"""Driver-visible fuzz: tests/fuzz_parity.py -- the randomised differential check of every drop-in
+against the oracle, random shapes around the edges the kernels switch on -- used to be run by hand only.  Here it runs
+bounded under `pytest -m gpu`: fixed seeds, four dask-style caller threads, about a minute; then the four newest kinds
+(22-25: xcorr of unequal lengths, per-sample phase arrays, CFAR of the complex map, the two-channel front end:
+signal_utils.py:24-32, target_detection.py:683-703, main.py:105-166) on their own.  A failure prints the case
+descriptors (kind, sizes) and the command that reproduces the run."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _fuzz(seed, seconds, threads, kinds=None):
+    env = dict(os.environ)
+    env.pop("PR_FUZZ_KINDS", None)
+    if kinds:
+        env["PR_FUZZ_KINDS"] = kinds
+    cmd = [sys.executable, os.path.join("tests", "fuzz_parity.py"), str(seed), str(seconds), str(threads)]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=seconds * 6 + 600)
+    how = (f"PR_FUZZ_KINDS={kinds} " if kinds else "") + " ".join(["python"] + cmd[1:]) + "   (from the repo root)"
+    tail = r.stdout[-3000:]
+    assert r.returncode == 0 and "FAILURES: none" in r.stdout, f"fuzz failed; reproduce with: {how}\n{tail}\n{r.stderr[-1500:]}"
+    ncase = int(r.stdout.split(" random cases")[0].split()[-1])
+    return ncase, tail
+
+
+def test_fuzz_all_kinds_four_threads(gpu_ready):
+    ncase, tail = _fuzz(seed=606, seconds=45, threads=4)
+    assert ncase >= 100, tail                     # the run really exercised the drop-ins (hundreds of cases on an MI355X)
+
+
+def test_fuzz_newest_kinds(gpu_ready):
+    ncase, tail = _fuzz(seed=607, seconds=15, threads=2, kinds="22,23,24,25")
+    assert ncase >= 20, tail

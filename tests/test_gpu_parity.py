@@ -129,6 +129,28 @@ def test_xcorr_and_freqshift():
         assert np.abs(y[::st] - gf[key]).max() < 2e-6
 
 
+def test_direct_xambg_drop_in():
+    """a user who swaps the import line finds direct_xambg (range_doppler_processing.py:93-124) too -- a
+    composition of prc_frequency_shift + prc_xcorr on device buffers, against the golden made by the reference; same
+    shape, dtype, axis convention (rows NOT mirrored) and ValueError as the reference."""
+    from passiveradar_amd.range_doppler_processing import direct_xambg
+    g = load_golden("direct_xambg")
+    for t in "ab":
+        out = direct_xambg(g[f"ref_{t}"], g[f"srv_{t}"], int(g[f"R_{t}"]), int(g[f"F_{t}"]), float(g[f"fs_{t}"]))
+        want = g[f"out_{t}"]
+        assert out.shape == want.shape and out.dtype == np.complex64
+        assert rel_err(out, want) < TIGHT, t
+        assert np.unravel_index(np.abs(out).argmax(), out.shape) == np.unravel_index(np.abs(want).argmax(), want.shape)
+    # SURVEY App. A6: an echo at delay 7, Doppler +5 bins peaks at row F/2 + 5 (fast_xambg: F/2 - 5), column R - 7
+    n, R, F = 4096, 20, 64
+    ref = scene.white_reference(n, 11)
+    srv = (np.roll(ref, 7) * np.exp(2j * np.pi * 5 * np.arange(n) / n)).astype(np.complex64)
+    D = np.abs(direct_xambg(ref, srv, R, F, float(n))[:, :, 0])
+    assert np.unravel_index(D.argmax(), D.shape) == (F // 2 + 5, R - 7)
+    with pytest.raises(ValueError, match="same length"):
+        direct_xambg(ref, srv[:-1], R, F, float(n))
+
+
 def test_xcorr_of_unequal_lengths_and_phase_arrays():
     """argument forms the reference's expressions accept -- xcorr of two signals of different lengths
     (signal_utils.py:29-32) and frequency_shift with one phase per sample (signal_utils.py:24-27), against goldens made

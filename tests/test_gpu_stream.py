@@ -634,3 +634,55 @@ def test_bench_gpus_n_starts_n_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["rccl_nranks"] == 2 and len(d["rank_ms_per_step"]) == 2, d
+
+
+def test_device_maps_through_the_output_stores(tmp_path):
+    """SURVEY 8 row f4 (main.py:200-224), device side: the maps of a small stream computed on the GPU go through BOTH
+    stores -- the zarr v2 directory store (frame by frame through ZarrFrameWriter, in two blocks out of order, as the
+    pipelined host-to-host step writes them) and the HDF5 dataset '/xambg' -- and come back, through the spec-driven zarr
+    reader and libhdf5, as the (F, R+1, nframes) array of the reference: equal to the device maps moved to axis 2, bit for
+    bit, and to the reference's own output of the same stream (golden `stream`) within the parity bar.  The .npz axes
+    follow main.py:200-206's formulas.  (No zarr / h5py consumer exists in this image: README, "Output stores".)"""
+    import json
+    import torch
+    from passiveradar_amd import output
+    from passiveradar_amd.stream import HipBackend, StreamProcessor
+    g = load_golden("stream")
+    C, R, F, fs = int(g["C"]), int(g["R"]), int(g["F"]), float(g["fs"])
+    sp = StreamProcessor(HipBackend(2 * C, R, F, fs, batch=4))
+    frames = sp.process(g["ref"], g["srv"])                       # device tensor [nframes][F][R+1]
+    assert frames.is_cuda and frames.dtype == torch.complex64
+    nframes = int(frames.shape[0])
+    want = np.ascontiguousarray(StreamProcessor.to_reference_layout(frames).cpu().numpy())
+    assert want.shape == (F, R + 1, nframes) == g["out"].shape
+    cfg = dict(num_doppler_cells=F, num_range_cells=R, frame_interval=C / fs, range_cell_width=299792458.0 / fs / 1000.0,
+               doppler_cell_width=fs / (2 * C), range_doppler_map_ftype="zarr",
+               range_doppler_map_fname=str(tmp_path / "XAMBG.zarr"), meta_fname=str(tmp_path / "XAMBG.npz"))
+    # zarr, as bench.py --workload prconfig stores: blocks of frames as they leave the device, here the second block first
+    zw = output.ZarrFrameWriter(cfg["range_doppler_map_fname"], F, R + 1, nframes)
+    cut = nframes // 2
+    host = torch.empty((nframes, F, R + 1), dtype=torch.complex64).pin_memory()
+    host[cut:].copy_(frames[cut:], non_blocking=True)
+    host[:cut].copy_(frames[:cut], non_blocking=True)
+    torch.cuda.synchronize()
+    zw.write(cut, host.numpy()[cut:])
+    zw.write(0, host.numpy()[:cut])
+    back = output.read_zarr_v2(cfg["range_doppler_map_fname"])
+    assert back.dtype == np.complex64 and np.array_equal(back, want)
+    assert rel_err(back, g["out"]) < 1e-4                          # what the reference itself stored for this stream
+    # the one-call form takes the device tensor directly
+    p2 = output.save_range_doppler(dict(cfg, range_doppler_map_fname=str(tmp_path / "again.zarr")), frames)
+    assert np.array_equal(output.load_range_doppler_zarr(p2), want)
+    meta = json.load(open(os.path.join(p2, ".zarray")))
+    assert meta["shape"] == [F, R + 1, nframes] and meta["chunks"] == [F, R + 1, 1] and meta["dtype"] == "<c8"
+    # HDF5 through the HDF5 C library
+    if output.hdf5_available():
+        ph = output.save_range_doppler(dict(cfg, range_doppler_map_ftype="hdf5", range_doppler_map_fname=str(tmp_path / "XAMBG.hdf5")),
+                                       frames.cpu().numpy())
+        got = output.load_range_doppler_hdf5(ph)
+        assert got.dtype == np.complex64 and np.array_equal(got, want)
+    # the .npz axes: main.py:200-206
+    m = np.load(output.save_metadata(cfg, nframes))
+    assert np.array_equal(m["frame_timestamps"], np.arange(nframes) * cfg["frame_interval"])
+    assert np.array_equal(m["range_bins"], np.arange(R + 1) * cfg["range_cell_width"])
+    assert np.array_equal(m["doppler_bins"], np.arange(-F, F) * cfg["doppler_cell_width"])

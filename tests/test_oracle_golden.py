@@ -46,6 +46,17 @@ def test_caf_axis_conventions():
     assert np.unravel_index(D.argmax(), D.shape) == (F // 2 + 5, R - 7)
 
 
+def test_direct_xambg_against_the_reference():
+    """range_doppler_processing.py:93-124, golden made by the reference (oracle/gen_golden.py direct_xambg_case)"""
+    g = load_golden("direct_xambg")
+    for t in "ab":
+        out = O.direct_xambg(g[f"ref_{t}"], g[f"srv_{t}"], int(g[f"R_{t}"]), int(g[f"F_{t}"]), float(g[f"fs_{t}"]))
+        assert out.shape == g[f"out_{t}"].shape and out.dtype == np.complex64
+        assert rel_err(out, g[f"out_{t}"]) < 2e-6
+    with pytest.raises(ValueError):
+        O.direct_xambg(np.zeros(8, np.complex64), np.zeros(9, np.complex64), 1, 2, 1.0)
+
+
 def test_caf_shape_error():
     with pytest.raises(ValueError):
         O.fast_xambg(np.zeros(8, np.complex64), np.zeros(9, np.complex64), 1, 2)
