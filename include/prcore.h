@@ -108,7 +108,10 @@ typedef enum prc_option {
                                      tap rows at full width; N > 0 = runs of about equal cost (2 w + N per two rows), each run
                                      multiplying only the w output columns its rows reach (37 % fewer multiply-adds at 13:119;
                                      measured no faster at any N, 7 % slower at N = 8: A/B runs)                             */
-    PRC_OPT_COUNT_ = 13
+    PRC_OPT_CAF_TEAM8 = 13,       /* 4096-point CAF segment kernel, read per launch: 0 = teams of four wavefronts, 16 points per
+                                     thread (three wavefronts per SIMD); 1 = teams of EIGHT wavefronts, 8 points per thread (six per
+                                     SIMD, a third LDS exchange per transform); default: the measured choice  */
+    PRC_OPT_COUNT_ = 14
 } prc_option;
 int prc_set_option(int32_t option, int64_t value);     /* PRC_EINVAL for an unknown option or a value out of range */
 int prc_get_option(int32_t option, int64_t* value);

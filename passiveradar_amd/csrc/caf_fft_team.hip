@@ -63,25 +63,6 @@ int ft_device_tables(const float2** out) {
 }
 
 
-struct CafTeamArgs {
-    CafSegArgs s;
-    const float2* gtab;
-    int32_t piece;      // B = 4097 - lagblk samples of ref per transform
-    int32_t lagblk;     // lags per block (<= 3073)
-    int32_t nlagblk;    // lag blocks covering 0..range_bins
-    int32_t segs;       // consecutive slow-time samples per workgroup
-    // several reference channels in ONE launch (nothing shared between them but the L2 -- "turns" without the tail of four
-    // small launches): channel z reads refs[z] and writes its surfaces y_ref_stride elements further on
-    const float2* refs[PRC_CAF_MAX_REFS];
-    int64_t y_ref_stride;
-    int32_t nref, chunks_x, nchunks;   // channels; workgroup chunks per frame; chunks_x * nframes
-    int32_t xcd_contig;                // 1: an XCD takes a contiguous run of chunks; 0: chunks go round the XCDs in launch order
-    int32_t pair_half;                 // > 0: frames overlap by half (= this many chunks): the two frames that cover the same
-                                       // samples run in consecutive slots of one XCD (PRC_OPT_CAF_PAIR_FRAMES)
-    int32_t nframes;
-};
-
-
 #ifndef CAFT_WAVES_PER_SIMD
 #define CAFT_WAVES_PER_SIMD 2
 #endif
@@ -343,6 +324,7 @@ int caf_launch_fft_team_refs(const CafSegArgs& s, const float2* const* refs, int
     }
     dim3 grid(a.pair_half > 0 ? (unsigned)(8 * (((nframes + 1) * a.pair_half + 7) / 8) * 2 * nref)
                               : (unsigned)(8 * ((a.nchunks + 7) / 8) * nref));
+    if (prc_opt(PRC_OPT_CAF_TEAM8)) return caf_launch_fft_team8(a, grid, s.window != nullptr, stream);
     const size_t lds = sizeof(float2) * FT_LDS_ELEMS;
     { int rc_ = prc_lds_optin(reinterpret_cast<const void*>(s.window ? &caf_fft_team_kernel<true> : &caf_fft_team_kernel<false>), (int)lds); if (rc_) return rc_; }
     if (s.window)

@@ -3,6 +3,28 @@
 #include "caf_internal.h"
 #include "fft_team.h"
 
+struct CafTeamArgs {
+    CafSegArgs s;
+    const float2* gtab;
+    int32_t piece;      // B = 4097 - lagblk samples of ref per transform
+    int32_t lagblk;     // lags per block (<= 3073)
+    int32_t nlagblk;    // lag blocks covering 0..range_bins
+    int32_t segs;       // consecutive slow-time samples per workgroup
+    // several reference channels in ONE launch (nothing shared between them but the L2 -- "turns" without the tail of four
+    // small launches): channel z reads refs[z] and writes its surfaces y_ref_stride elements further on
+    const float2* refs[PRC_CAF_MAX_REFS];
+    int64_t y_ref_stride;
+    int32_t nref, chunks_x, nchunks;   // channels; workgroup chunks per frame; chunks_x * nframes
+    int32_t xcd_contig;                // 1: an XCD takes a contiguous run of chunks; 0: chunks go round the XCDs in launch order
+    int32_t pair_half;                 // > 0: frames overlap by half (= this many chunks): the two frames that cover the same
+                                       // samples run in consecutive slots of one XCD (PRC_OPT_CAF_PAIR_FRAMES)
+    int32_t nframes;
+};
+
+// the same segment kernel on the eight-wavefront transform of fft_team8.h (caf_fft_team8.hip); `a` as prepared by
+// caf_launch_fft_team_refs
+int caf_launch_fft_team8(const CafTeamArgs& a, dim3 grid, bool has_window, hipStream_t stream);
+
 #define CAFT_TAIL_MAX 16      // a last piece of at most this many samples is added directly after the inverse transform
 
 // Direct lag products of the `tail` samples after the last full piece (acc is the unnormalised inverse transform,

@@ -789,11 +789,15 @@ def test_nlms_reference_level_step():
 
 
 # ---- 4096-point team transforms (caf_fft_team.hip): forced through the plan, every branch of the kernel ----
-@pytest.fixture
-def caf_team():
-    from passiveradar_amd import range_doppler_processing as rdp
+@pytest.fixture(params=[0, 1], ids=["four_waves_16_points", "eight_waves_8_points"])
+def caf_team(request):
+    """both forms of the 4096-point segment kernel: teams of four wavefronts (fft_team.h) and of eight (fft_team8.h,
+    PRC_OPT_CAF_TEAM8, read per launch)"""
+    from passiveradar_amd import _lib, range_doppler_processing as rdp
     rdp.set_default_methods(caf=3)
+    old = _lib.set_option(_lib.OPT_CAF_TEAM8, request.param)
     yield
+    _lib.set_option(_lib.OPT_CAF_TEAM8, old)
     rdp.set_default_methods(caf=0)
 
 

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--tag", default="")
     ap.add_argument("--pair-frames", type=int, default=None, help="PRC_OPT_CAF_PAIR_FRAMES: 0 or 1")
     ap.add_argument("--xcd-contig", type=int, default=None, help="PRC_OPT_CAF_XCD_CONTIG: 0 or 1")
+    ap.add_argument("--team8", type=int, default=None, help="PRC_OPT_CAF_TEAM8: 0 = teams of four wavefronts, 1 = of eight")
     ap.add_argument("--long-fir", action="store_true", help="shortFilt=False: firwin(10 q + 1, 1/q, flattop) instead of the boxcar")
     args = ap.parse_args()
     import torch
@@ -45,6 +46,8 @@ def main():
         _lib.set_option(_lib.OPT_CAF_PAIR_FRAMES, args.pair_frames)
     if args.xcd_contig is not None:
         _lib.set_option(_lib.OPT_CAF_XCD_CONTIG, args.xcd_contig)
+    if args.team8 is not None:
+        _lib.set_option(_lib.OPT_CAF_TEAM8, args.team8)
     n, R, F = SHAPES[args.shape]
     C = n // 2
     nf, nref = args.frames, args.nref
@@ -80,7 +83,7 @@ def main():
         return float(np.median(ts))
 
     res = {"lib": os.environ.get("PRCORE_LIB", "default"), "tag": args.tag, "shape": args.shape, "frames": nf,
-           "nref": nref, "long_fir": bool(args.long_fir), "xcd_contig": args.xcd_contig, "pair_frames": args.pair_frames, "method": plan.method, "doppler": plan.doppler, "multi": plan.multi}
+           "nref": nref, "long_fir": bool(args.long_fir), "xcd_contig": args.xcd_contig, "pair_frames": args.pair_frames, "team8": _lib.get_option(_lib.OPT_CAF_TEAM8), "method": plan.method, "doppler": plan.doppler, "multi": plan.multi}
     res["segments_ms"] = timeit(lambda: plan.execute_segments(refs[0], srv, nf, C, n, win, s))
     res["doppler_ms"] = timeit(lambda: plan.execute_doppler(outs[0], nf, s))
     res["execute_ms"] = timeit(lambda: plan.execute(refs[0], srv, outs[0], nf, C, n, win, s))
