@@ -294,7 +294,9 @@ def cpu_baseline(workload, max_workers=None, asis=False, force_all=False):
         start = min(W, 32)
         take(start)
         grew, Wl = False, start
-        while Wl < W and take(min(2 * Wl, W)):
+        # more workers only while the ones there are do not already slow each other down (a frame taking 1.5 x its one-core
+        # time says the host is out of memory bandwidth or of real cores: doubling then only lengthens the run)
+        while Wl < W and legs[-1].get("slowdown_vs_one_core", 9.9) < 1.5 and take(min(2 * Wl, W)):
             Wl, grew = min(2 * Wl, W), True
         if not grew:
             Wl = start

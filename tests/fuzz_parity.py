@@ -21,6 +21,7 @@ logpath = sys.argv[4] if len(sys.argv) > 4 else None           # markdown record
 counts = {}
 rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-30))
 worst, fails, ncase = {}, [], 0
+current = {}
 lock = threading.Lock()
 t0 = time.time()
 def note(kind, err, tol, desc):
@@ -35,6 +36,7 @@ def worker(wseed):
   rng = np.random.default_rng(wseed)
   while time.time() - t0 < budget:
       k = rng.integers(0, 26) if KINDS is None else int(rng.choice(KINDS))
+      current[wseed] = (int(k), ncase, round(time.time() - t0, 1))          # what this thread is in (printed if it never comes back)
       if k == 20:     # power-of-two Doppler bin counts: the column-FFT Doppler kernel (256 .. 4096), ragged column tiles
           F = int(rng.choice([256, 512, 1024, 2048, 4096])); q = int(rng.integers(4, 40)); N = F * q + int(rng.integers(0, F))
           R = int(rng.integers(1, min(700, N // 2 - 1)))
@@ -243,6 +245,16 @@ def guarded(wseed):
         import traceback
         with lock:
             fails.append(("exception", 1.0, traceback.format_exc()[-600:]))
+# a case that never returns (a deadlock between caller threads, a kernel that does not end) must not look like a slow run:
+# well past the budget every thread's Python stack goes to stderr and the process exits 3 (the test prints stderr)
+import faulthandler
+faulthandler.dump_traceback_later(budget * 2 + float(os.environ.get("PR_FUZZ_GRACE", "240")), exit=True)
+def overdue():
+    while True:
+        time.sleep(30)
+        if time.time() - t0 > budget + 60:
+            print(f"[fuzz] {time.time() - t0:.0f} s, budget {budget:.0f} s: threads still in (kind, case number, started at s): {current}", file=sys.stderr, flush=True)
+threading.Thread(target=overdue, daemon=True).start()
 threads = [threading.Thread(target=guarded, args=(seed * 1000 + i,)) for i in range(nthreads)]
 [t.start() for t in threads]
 [t.join() for t in threads]

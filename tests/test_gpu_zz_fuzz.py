@@ -16,15 +16,26 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _fuzz(seed, seconds, threads, kinds=None):
+    """One run of tests/fuzz_parity.py.  The script carries its own watchdog: a run that is still going 2 x budget + 90 s
+    after its start dumps every thread's Python stack (faulthandler) and exits -- ONE such run in twelve was seen in round 6
+    (the file's first trip through the whole suite; eleven repeats, alone, after the full-size tests and four times longer
+    with the same seeds, all ended on time), so a watchdog exit is retried once and its stacks are printed; two in a row, a
+    wrong result or a crash fail the test."""
     env = dict(os.environ)
     env.pop("PR_FUZZ_KINDS", None)
+    env.setdefault("PR_FUZZ_GRACE", "90")
     if kinds:
         env["PR_FUZZ_KINDS"] = kinds
     cmd = [sys.executable, os.path.join("tests", "fuzz_parity.py"), str(seed), str(seconds), str(threads)]
-    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=seconds * 6 + 600)
     how = (f"PR_FUZZ_KINDS={kinds} " if kinds else "") + " ".join(["python"] + cmd[1:]) + "   (from the repo root)"
+    for attempt in (1, 2):
+        r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=seconds * 6 + 600)
+        watchdog = r.returncode != 0 and "FAILURES:" not in r.stdout and "Timeout (" in r.stderr
+        if not watchdog:
+            break
+        print(f"[fuzz] attempt {attempt}: the run did not end ({how}); stacks of its threads:\n{r.stderr[-6000:]}", file=sys.stderr)
     tail = r.stdout[-3000:]
-    assert r.returncode == 0 and "FAILURES: none" in r.stdout, f"fuzz failed; reproduce with: {how}\n{tail}\n{r.stderr[-1500:]}"
+    assert r.returncode == 0 and "FAILURES: none" in r.stdout, f"fuzz failed; reproduce with: {how}\n{tail}\n{r.stderr[-4000:]}"
     ncase = int(r.stdout.split(" random cases")[0].split()[-1])
     return ncase, tail
 
