@@ -517,6 +517,16 @@ struct prc_frontend_plan {
     prc_frontend_desc desc;
     float* d_taps = nullptr;     // polyphase layout
     double* d_phases = nullptr;  // max_blocks
+    // The caller's phases_host array may be a temporary that is gone when the call returns (the ctypes array of
+    // engine.FrontendPlan.execute is), and an asynchronous copy from PAGEABLE memory may read its source only when the
+    // stream gets there (round 6: tests/fuzz_parity.py, eight caller threads: a block tuned with another call's phases).
+    // So the phases are copied into pinned memory the plan owns before the call returns -- a ring of slots, each guarded by
+    // an event recorded behind its device copy, so that a slot is never rewritten while a copy out of it is still queued.
+    static constexpr int PH_SLOTS = 8;
+    double* h_phases = nullptr;  // pinned, PH_SLOTS x max_blocks
+    hipEvent_t ph_ev[PH_SLOTS] = {};
+    bool ph_used[PH_SLOTS] = {};
+    int ph_next = 0;
     float* d_T = nullptr;        // group form: tap rows (nullptr: up > 16 or the window does not fit LDS)
     FegArgs g = {};
     size_t g_lds = 0;
@@ -531,6 +541,9 @@ extern "C" int prc_frontend_plan_destroy(prc_frontend_plan* p) {
     if (!p) return PRC_OK;
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_phases) (void)hipFree(p->d_phases);
+    if (p->h_phases) (void)hipHostFree(p->h_phases);
+    for (hipEvent_t ev : p->ph_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (p->d_T) (void)hipFree(p->d_T);
     delete p;
     return PRC_OK;
@@ -558,6 +571,8 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
     hipError_t e = hipMalloc(&p->d_taps, sizeof(float) * poly.size());
     if (e == hipSuccess) e = hipMemcpy(p->d_taps, poly.data(), sizeof(float) * poly.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->d_phases, sizeof(double) * d->max_blocks);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_phases, sizeof(double) * d->max_blocks * prc_frontend_plan::PH_SLOTS, hipHostMallocDefault);
+    for (int i = 0; i < prc_frontend_plan::PH_SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ph_ev[i], hipEventDisableTiming);
     // the group form's tables: row = r_hi - r, T[row][q] = hz[s_q - up r], s_q = (q + n_pre_remove) dn
     if (e == hipSuccess && d->up <= 16) {
         const int64_t up = d->up, dn = d->down;
@@ -715,7 +730,14 @@ static int frontend_run(prc_frontend_plan* p, const void* raw, const void* raw2,
     a.taps = p->d_taps;
     a.phases = nullptr;
     if (mix && phases_host) {
-        PRC_HIP(hipMemcpyAsync(p->d_phases, phases_host, sizeof(double) * nblocks, hipMemcpyHostToDevice, stream));
+        const int slot = p->ph_next;
+        p->ph_next = (slot + 1) % prc_frontend_plan::PH_SLOTS;
+        if (p->ph_used[slot]) PRC_HIP(hipEventSynchronize(p->ph_ev[slot]));      // the copy that last read this slot (8 calls ago) is done
+        double* hp = p->h_phases + (size_t)slot * p->desc.max_blocks;
+        memcpy(hp, phases_host, sizeof(double) * nblocks);                          // the caller's array is not touched after this line
+        PRC_HIP(hipMemcpyAsync(p->d_phases, hp, sizeof(double) * nblocks, hipMemcpyHostToDevice, stream));
+        PRC_HIP(hipEventRecord(p->ph_ev[slot], stream));
+        p->ph_used[slot] = true;
         a.phases = p->d_phases;
     }
     a.raw_stride = raw_stride;

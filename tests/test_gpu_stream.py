@@ -686,3 +686,39 @@ def test_device_maps_through_the_output_stores(tmp_path):
     assert np.array_equal(m["frame_timestamps"], np.arange(nframes) * cfg["frame_interval"])
     assert np.array_equal(m["range_bins"], np.arange(R + 1) * cfg["range_cell_width"])
     assert np.array_equal(m["doppler_bins"], np.arange(-F, F) * cfg["doppler_cell_width"])
+
+
+def test_front_end_phases_may_die_when_the_call_returns():
+    """Round 6 (found by tests/fuzz_parity.py under eight caller threads: a block tuned with another call's phases):
+    prc_frontend_execute's `phases_host` is a HOST array the caller may free the moment the call returns -- the ctypes
+    array of engine.FrontendPlan.execute is such a temporary -- while the stream may reach the copy much later.  Here
+    the stream is kept busy (a long sleep kernel queued first), the call is made through the C ABI with phases in a buffer
+    that is overwritten right after it returns, and the blocks must come out tuned with the phases that were passed
+    (main.py:125-149); nine calls in a row also take the plan's ring of pinned slots round once."""
+    import ctypes as C
+    import torch
+    from passiveradar_amd import _lib, engine
+    from passiveradar_amd import scene
+    n_in, up, dn, nb = 6000, 13, 119, 4
+    raw = scene.make_raw_stream(nb, 2 * n_in, 2400000, 100000, scene.scene_seed(77))[0]
+    raw_d = torch.from_numpy(raw).cuda()
+    plan = engine.FrontendPlan(n_in, "int8", up, dn, nb)
+    lib, s = _lib.lib(), _lib.torch_stream_ptr()
+    good = [0.3 + 1.7 * b for b in range(nb)]
+
+    def run(phases_buf, out):
+        _lib.check(lib.prc_frontend_execute(plan._h, raw_d.data_ptr(), 2 * n_in, 1, 100000.0, 2400000.0, phases_buf, out.data_ptr(),
+                                            plan.n_out, nb, s))
+    want = torch.empty(nb * plan.n_out, dtype=torch.complex64, device="cuda")
+    keep = (C.c_double * nb)(*good)
+    run(keep, want)
+    torch.cuda.synchronize()
+    for rounds in range(9):
+        got = torch.zeros_like(want)
+        torch.cuda._sleep(400_000_000)                       # ~0.2 s of stream time before the copy can run
+        buf = (C.c_double * nb)(*good)
+        run(buf, got)
+        for b in range(nb):
+            buf[b] = 1e9 + b                                   # the caller's memory is reused at once
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), rounds
