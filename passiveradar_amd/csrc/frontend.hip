@@ -729,6 +729,12 @@ static int frontend_run(prc_frontend_plan* p, const void* raw, const void* raw2,
     a.out2 = (float2*)out2;
     a.taps = p->d_taps;
     a.phases = nullptr;
+#ifdef FE_EXP_PHASES_DIRECT     // the form of rounds 3-5, kept for the regression test's A/B only: asynchronous copy straight from the caller's array
+    if (mix && phases_host) {
+        PRC_HIP(hipMemcpyAsync(p->d_phases, phases_host, sizeof(double) * nblocks, hipMemcpyHostToDevice, stream));
+        a.phases = p->d_phases;
+    }
+#else
     if (mix && phases_host) {
         const int slot = p->ph_next;
         p->ph_next = (slot + 1) % prc_frontend_plan::PH_SLOTS;
@@ -740,6 +746,7 @@ static int frontend_run(prc_frontend_plan* p, const void* raw, const void* raw2,
         p->ph_used[slot] = true;
         a.phases = p->d_phases;
     }
+#endif
     a.raw_stride = raw_stride;
     a.out_stride = out_stride;
     a.n_in = p->n_in;

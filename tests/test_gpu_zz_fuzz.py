@@ -48,3 +48,13 @@ def test_fuzz_all_kinds_four_threads(gpu_ready):
 def test_fuzz_newest_kinds(gpu_ready):
     ncase, tail = _fuzz(seed=607, seconds=15, threads=2, kinds="22,23,24,25")
     assert ncase >= 20, tail
+
+
+def test_fuzz_two_channel_front_end_eight_threads(gpu_ready):
+    """Round 6: the one wrong result the fuzz has ever produced -- kind 25 (prc_frontend_execute2 against two
+    prc_frontend_execute calls, bit for bit) under EIGHT caller threads: the block phases travelled by an asynchronous copy
+    straight out of the caller's temporary array (about one case in sixty came back tuned with other phases; single-threaded
+    the runtime stages such a copy at once and nothing shows).  The plan now copies them into its own pinned ring before
+    the call returns (frontend.hip); 34 000 cases from eight threads since, none wrong."""
+    ncase, tail = _fuzz(seed=713, seconds=20, threads=8, kinds="25")
+    assert ncase >= 300, tail
