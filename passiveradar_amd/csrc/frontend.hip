@@ -41,7 +41,25 @@ struct FeArgs {
     int32_t opw;              // outputs per workgroup (<= FE_THREADS; fewer when the decimation ratio is large)
     int32_t src;              // prc_raw_dtype, for the group kernel (it branches on the type once per window)
     PhaseRamp pr;
+    // Block phases of a launch of up to FE_PH_INLINE blocks travel INSIDE the kernel arguments (round 6): the caller's host
+    // array is read while the call is being made and never again, and no copy command is queued anywhere -- an asynchronous
+    // copy out of the caller's (temporary, pageable) array was a use-after-return under eight caller threads, and a copy
+    // out of pinned plan memory put a DMA command on the compute stream that queued behind the recordings' 150 MB
+    // host-to-device copies (host-to-host step 206 -> 324 ms).  Longer launches fill d_phases with small kernels whose
+    // ARGUMENTS carry the values (fe_set_phases_kernel).
+    int32_t ph_n;             // > 0: ph_inline holds this launch's block phases
+    double ph_inline[32];
 };
+#define FE_PH_INLINE 32
+struct FePhChunk { double v[FE_PH_INLINE]; int32_t n; };
+__global__ void fe_set_phases_kernel(FePhChunk c, double* dst) {
+    if ((int)threadIdx.x < c.n) dst[threadIdx.x] = c.v[threadIdx.x];
+}
+__device__ __forceinline__ double fe_block_phase(const FeArgs& a, int b) {
+    if (!a.mix) return 0.0;
+    if (a.ph_n > 0) return a.ph_inline[b];
+    return a.phases ? a.phases[b] : 0.0;
+}
 #define FE_SRC_RT 99      // fe_block<FE_SRC_RT>: the block's base address from FeArgs.src
 
 template <int SRC>
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(FeArgs a) {
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const void* raw = fe_block<SRC>(a, b);
-    const double blk_phase = (a.mix && a.phases) ? a.phases[b] : 0.0;
+    const double blk_phase = fe_block_phase(a, b);
     for (int i = tid; i < a.J * a.up; i += FE_THREADS) H[i] = a.taps[i];
 
     // outputs of this workgroup and the input span they touch
@@ -457,7 +475,7 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
         a2.raw = a.raw2;
         raw[NCH - 1] = fe_block<FE_SRC_RT>(a2, b);
     }
-    const double blk_phase = (a.mix && a.phases) ? a.phases[b] : 0.0;
+    const double blk_phase = fe_block_phase(a, b);
     const int64_t N0 = (int64_t)blockIdx.x * G;                     // first group of the workgroup
     const int64_t i_w = N0 * a.dn + g.r_first;                      // input index of the window's first sample
     switch (a.src) {            // one scalar branch per window, not per sample
@@ -517,16 +535,6 @@ struct prc_frontend_plan {
     prc_frontend_desc desc;
     float* d_taps = nullptr;     // polyphase layout
     double* d_phases = nullptr;  // max_blocks
-    // The caller's phases_host array may be a temporary that is gone when the call returns (the ctypes array of
-    // engine.FrontendPlan.execute is), and an asynchronous copy from PAGEABLE memory may read its source only when the
-    // stream gets there (round 6: tests/fuzz_parity.py, eight caller threads: a block tuned with another call's phases).
-    // So the phases are copied into pinned memory the plan owns before the call returns -- a ring of slots, each guarded by
-    // an event recorded behind its device copy, so that a slot is never rewritten while a copy out of it is still queued.
-    static constexpr int PH_SLOTS = 8;
-    double* h_phases = nullptr;  // pinned, PH_SLOTS x max_blocks
-    hipEvent_t ph_ev[PH_SLOTS] = {};
-    bool ph_used[PH_SLOTS] = {};
-    int ph_next = 0;
     float* d_T = nullptr;        // group form: tap rows (nullptr: up > 16 or the window does not fit LDS)
     FegArgs g = {};
     size_t g_lds = 0;
@@ -541,9 +549,6 @@ extern "C" int prc_frontend_plan_destroy(prc_frontend_plan* p) {
     if (!p) return PRC_OK;
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_phases) (void)hipFree(p->d_phases);
-    if (p->h_phases) (void)hipHostFree(p->h_phases);
-    for (hipEvent_t ev : p->ph_ev)
-        if (ev) (void)hipEventDestroy(ev);
     if (p->d_T) (void)hipFree(p->d_T);
     delete p;
     return PRC_OK;
@@ -571,8 +576,6 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
     hipError_t e = hipMalloc(&p->d_taps, sizeof(float) * poly.size());
     if (e == hipSuccess) e = hipMemcpy(p->d_taps, poly.data(), sizeof(float) * poly.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&p->d_phases, sizeof(double) * d->max_blocks);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&p->h_phases, sizeof(double) * d->max_blocks * prc_frontend_plan::PH_SLOTS, hipHostMallocDefault);
-    for (int i = 0; i < prc_frontend_plan::PH_SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&p->ph_ev[i], hipEventDisableTiming);
     // the group form's tables: row = r_hi - r, T[row][q] = hz[s_q - up r], s_q = (q + n_pre_remove) dn
     if (e == hipSuccess && d->up <= 16) {
         const int64_t up = d->up, dn = d->down;
@@ -729,22 +732,27 @@ static int frontend_run(prc_frontend_plan* p, const void* raw, const void* raw2,
     a.out2 = (float2*)out2;
     a.taps = p->d_taps;
     a.phases = nullptr;
-#ifdef FE_EXP_PHASES_DIRECT     // the form of rounds 3-5, kept for the regression test's A/B only: asynchronous copy straight from the caller's array
+    a.ph_n = 0;
+#ifdef FE_EXP_PHASES_DIRECT     // the form of rounds 3-5, kept for A/B runs only: asynchronous copy straight from the caller's array
     if (mix && phases_host) {
         PRC_HIP(hipMemcpyAsync(p->d_phases, phases_host, sizeof(double) * nblocks, hipMemcpyHostToDevice, stream));
         a.phases = p->d_phases;
     }
 #else
     if (mix && phases_host) {
-        const int slot = p->ph_next;
-        p->ph_next = (slot + 1) % prc_frontend_plan::PH_SLOTS;
-        if (p->ph_used[slot]) PRC_HIP(hipEventSynchronize(p->ph_ev[slot]));      // the copy that last read this slot (8 calls ago) is done
-        double* hp = p->h_phases + (size_t)slot * p->desc.max_blocks;
-        memcpy(hp, phases_host, sizeof(double) * nblocks);                          // the caller's array is not touched after this line
-        PRC_HIP(hipMemcpyAsync(p->d_phases, hp, sizeof(double) * nblocks, hipMemcpyHostToDevice, stream));
-        PRC_HIP(hipEventRecord(p->ph_ev[slot], stream));
-        p->ph_used[slot] = true;
-        a.phases = p->d_phases;
+        if (nblocks <= FE_PH_INLINE) {
+            memcpy(a.ph_inline, phases_host, sizeof(double) * nblocks);
+            a.ph_n = nblocks;
+        } else {
+            for (int b0 = 0; b0 < nblocks; b0 += FE_PH_INLINE) {
+                FePhChunk c;
+                c.n = nblocks - b0 < FE_PH_INLINE ? nblocks - b0 : FE_PH_INLINE;
+                memcpy(c.v, phases_host + b0, sizeof(double) * c.n);
+                hipLaunchKernelGGL(fe_set_phases_kernel, dim3(1), dim3(64), 0, stream, c, p->d_phases + b0);
+            }
+            PRC_LAUNCH_CHECK();
+            a.phases = p->d_phases;
+        }
     }
 #endif
     a.raw_stride = raw_stride;

@@ -694,14 +694,21 @@ def test_front_end_phases_may_die_when_the_call_returns():
     array of engine.FrontendPlan.execute is such a temporary -- while the stream may reach the copy much later.  Here
     the stream is kept busy (a long sleep kernel queued first), the call is made through the C ABI with phases in a buffer
     that is overwritten right after it returns, and the blocks must come out tuned with the phases that were passed
-    (main.py:125-149); nine calls in a row also take the plan's ring of pinned slots round once.  (Single-threaded the HIP
-    runtime stages a small pageable copy at enqueue, so this contract test also passes on the old direct copy -- measured;
-    the load that made it fail is in tests/test_gpu_zz_fuzz.py::test_fuzz_two_channel_front_end_eight_threads.)"""
+    (main.py:125-149).  The phases now ride inside the kernel arguments (up to 32 blocks per launch) or, for longer
+    launches, inside the arguments of small kernels that fill the plan's device array -- both forms are run here (4 and
+    70 blocks per launch).  (Single-threaded the HIP runtime stages a small pageable copy at enqueue, so this contract
+    test also passes on the old direct copy -- measured; the load that made it fail is in
+    tests/test_gpu_zz_fuzz.py::test_fuzz_two_channel_front_end_eight_threads.)"""
     import ctypes as C
     import torch
     from passiveradar_amd import _lib, engine
     from passiveradar_amd import scene
-    n_in, up, dn, nb = 6000, 13, 119, 4
+    for n_in, nb in ((6000, 4), (1500, 70)):
+        _phases_case(C, torch, _lib, engine, scene, n_in, nb)
+
+
+def _phases_case(C, torch, _lib, engine, scene, n_in, nb):
+    up, dn = 13, 119
     raw = scene.make_raw_stream(nb, 2 * n_in, 2400000, 100000, scene.scene_seed(77))[0]
     raw_d = torch.from_numpy(raw).cuda()
     plan = engine.FrontendPlan(n_in, "int8", up, dn, nb)
@@ -715,9 +722,14 @@ def test_front_end_phases_may_die_when_the_call_returns():
     keep = (C.c_double * nb)(*good)
     run(keep, want)
     torch.cuda.synchronize()
-    for rounds in range(9):
+    # the blocks really are tuned per block: with all phases equal to the first one the other blocks differ
+    flat = torch.empty_like(want)
+    run((C.c_double * nb)(*([good[0]] * nb)), flat)
+    torch.cuda.synchronize()
+    assert torch.equal(flat[:plan.n_out], want[:plan.n_out]) and not torch.equal(flat[plan.n_out:], want[plan.n_out:])
+    for rounds in range(3):
         got = torch.zeros_like(want)
-        torch.cuda._sleep(400_000_000)                       # ~0.2 s of stream time before the copy can run
+        torch.cuda._sleep(400_000_000)                       # ~0.2 s of stream time before the launch can run
         buf = (C.c_double * nb)(*good)
         run(buf, got)
         for b in range(nb):
