@@ -36,9 +36,10 @@ One JSON line on rank 0 (contract in the task statement) with these extra object
                  and the bytes moved; kernel_time_accounting relates their sums to ms_per_step
   cpu_baseline : the reference's CPU path (oracle restatement issuing the same NumPy/SciPy calls, SciPy-1.15 np.roots
                  artefact left out) MEASURED on this box's host cores: one core, and one frame per worker process on the
-                 worker count that gives the strongest figure (searched from 32 workers, doubling / halving while the
-                 throughput grows; every leg is listed; `--cpu-workers all` adds the leg on every usable core, which on the
-                 256-core hosts of this pool is five times WEAKER than 16 workers: profiles/r06_bench_default_allcore_legs.json)
+                 worker count that gives the strongest figure (usable cores = min(affinity, cgroup CPU quota): 16 on this
+                 pool's boxes, which report 256; searched from min(usable, 32) workers, doubling / halving while the
+                 throughput grows; every leg is listed; 256 workers measured five times WEAKER than 16:
+                 profiles/r06_bench_default_allcore_legs.json)
   secondary    : BASELINE configs 3 and 5, a few steps each in child processes (default single-GPU line only)
 """
 import argparse
@@ -274,12 +275,12 @@ def cpu_baseline(workload, max_workers=None, asis=False, force_all=False):
         legs.append(rec)
         return rec
     try:
-        # the x50 claim is against the STRONGEST CPU number.  More workers are not always stronger: on the
-        # MI355X box of this pool (256 logical cores reported, no cgroup quota visible) 256 workers made 0.45 frames/s, 128
-        # 0.64, 64 1.43, 32 2.01, 16 2.45 (profiles/r06_bench_default_allcore_legs.json: every worker slowed 97x .. 1.1x).
-        # So: start at min(usable cores, 32), double while the throughput still grows (up to every usable core), else
-        # halve while it grows; `value` is the best leg and every leg is listed.  --cpu-workers all forces the all-cores
-        # leg too.
+        # the x50 claim is against the STRONGEST CPU number.  More workers are not always stronger: the MI355X
+        # boxes of this pool report 256 logical cores and grant a cgroup CPU quota of 16 -- 256 workers made 0.45 frames/s,
+        # 128 0.64, 64 1.43, 32 2.01, 16 2.45 (profiles/r06_bench_default_allcore_legs.json, before _usable_cores read the
+        # quota: every worker slowed 97x .. 1.1x).  So: W = min(affinity, quota); start at min(W, 32), double while the
+        # workers do not slow each other down and the throughput still grows, else halve while it grows; `value` is the
+        # best leg and every leg is listed.  --cpu-workers all forces a leg on every usable core too.
         best = None
         tried = set()
 
