@@ -11,6 +11,16 @@ from passiveradar_amd.signal_utils import decimate_iir, deinterleave_IQ, find_ch
 from passiveradar_amd.target_detection import CFAR_2D, CFAR_2D_abs
 
 import os, threading
+# Everything the workers use is imported HERE, on the main thread, before they start.  Round 6: two runs in twenty-six did
+# not end -- a worker's first `import torch` (dlopen of torch's HIP libraries: holds the GIL and the dynamic loader's lock
+# while their static constructors register with the HIP runtime) met another worker inside prc_caf_plan_create (holds a
+# HIP runtime lock while it loads a code object, which needs the loader's lock): lock-order inversion between the two, and
+# the remaining workers waited for the GIL for ever (stacks: profiles/r06_fuzz_watchdog_stacks.md).
+try:
+    import torch                                                         # noqa: F401
+    from passiveradar_amd.stream import HipBackend, StreamProcessor      # noqa: F401
+except ImportError:
+    pass
 from passiveradar_amd import clutter_removal as _cr
 _cr.set_default_ls_method(int(os.environ.get("PR_FUZZ_LS_METHOD", "0")))      # e.g. 4: the LS kinds on the 4096-point chain
 KINDS = [int(x) for x in os.environ["PR_FUZZ_KINDS"].split(",")] if os.environ.get("PR_FUZZ_KINDS") else None

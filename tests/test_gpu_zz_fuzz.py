@@ -17,10 +17,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _fuzz(seed, seconds, threads, kinds=None):
     """One run of tests/fuzz_parity.py.  The script carries its own watchdog: a run that is still going 2 x budget + 90 s
-    after its start dumps every thread's Python stack (faulthandler) and exits -- ONE such run in twelve was seen in round 6
-    (the file's first trip through the whole suite; eleven repeats, alone, after the full-size tests and four times longer
-    with the same seeds, all ended on time), so a watchdog exit is retried once and its stacks are printed; two in a row, a
-    wrong result or a crash fail the test."""
+    after its start dumps every thread's Python stack (faulthandler) and exits.  Round 6 saw two such runs in twenty-six and
+    the stacks named the cause -- a worker thread's first `import torch` deadlocking with another worker's HIP call (dynamic
+    loader lock against HIP runtime lock; the script now imports everything on the main thread first) -- so a watchdog exit
+    is still retried once and its stacks are kept (gpurun_out/fuzz_watchdog_*.txt); two in a row, a wrong result or a
+    crash fail the test."""
     env = dict(os.environ)
     env.pop("PR_FUZZ_KINDS", None)
     env.setdefault("PR_FUZZ_GRACE", "90")
