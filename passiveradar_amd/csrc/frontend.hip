@@ -311,9 +311,25 @@ __device__ __forceinline__ void feg_stage_interior(const FeArgs& a, const FegArg
     // whole trips: the same number for every thread (a per-thread bound lets the first lanes of the workgroup take one trip
     // more than the rest: two of its wavefronts then run both forms, and everybody waits for them at the barrier)
     const int nfull = g.span / (FEG_THREADS * FEG_CHUNK);
+    // The few samples after the last whole trip (6 of 4102 at 13:119 with two channels) ride in that trip as ONE more load
+    // per thread (round 6): left to the general form below they cost every workgroup a second round trip to memory and
+    // eight rotations on its first wavefront alone, with the other seven waiting at the barrier.
+    const int rem = g.span - nfull * (FEG_THREADS * FEG_CHUNK);
+#ifdef FEG_EXP_TAIL_GENERAL        // the form of rounds 4-5, for A/B runs
+    const bool fold = false;
+#else
+    const bool fold = nfull > 0 && rem > 0 && rem <= FEG_THREADS;
+#endif
     int k0 = tid;
     for (int trip = 0; trip < nfull; ++trip, k0 += FEG_THREADS * FEG_CHUNK) {
         float2 v[NCH][FEG_CHUNK];
+        const bool extra = fold && trip == nfull - 1 && tid < rem;
+        const int kx = nfull * (FEG_THREADS * FEG_CHUNK) + tid;
+        float2 vx[NCH];
+        if (extra) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) vx[ch] = fe_load<SRC>(raw[ch], i_w + kx);
+        }
 #pragma unroll
         for (int c = 0; c < FEG_CHUNK; ++c) {
 #pragma unroll
@@ -346,8 +362,19 @@ __device__ __forceinline__ void feg_stage_interior(const FeArgs& a, const FegArg
             }
 #endif
         }
+        if (extra) {
+            const int at = feg_at<PAD>(a, g, kx);
+            if (MIX) {
+                const v2f tw = fe_twiddle(a, i_w + kx, blk_phase);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) X[ch * g.xstride + at] = fe_apply(vx[ch], tw);
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) X[ch * g.xstride + at] = vx[ch];
+            }
+        }
     }
-    feg_stage_general<SRC, NCH>(a, g, X, raw, i_w, blk_phase, k0, false);
+    if (!fold) feg_stage_general<SRC, NCH>(a, g, X, raw, i_w, blk_phase, k0, false);
 }
 template <int SRC, int NCH>
 __device__ __forceinline__ void feg_stage(const FeArgs& a, const FegArgs& g, float2* X, const void* const (&raw)[NCH], int64_t i_w,
