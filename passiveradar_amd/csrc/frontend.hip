@@ -503,6 +503,14 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
         raw[NCH - 1] = fe_block<FE_SRC_RT>(a2, b);
     }
     const double blk_phase = fe_block_phase(a, b);
+#ifdef FEG_EXP_STAGGER              // A/B, never shipped (round 6: 7.1-7.3 us per block-channel with 3 / 7 / 10 us of delay, 7.0-7.3 without):
+    {                               // the second workgroup of every CU in the first dispatch round starts late, so that the two
+                                    // workgroups of a CU are in different phases (staging against row loop) from then on
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin >= 256u && lin < 512u)
+            for (int i = 0; i < FEG_EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     const int64_t N0 = (int64_t)blockIdx.x * G;                     // first group of the workgroup
     const int64_t i_w = N0 * a.dn + g.r_first;                      // input index of the window's first sample
     switch (a.src) {            // one scalar branch per window, not per sample
