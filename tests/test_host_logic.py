@@ -284,7 +284,24 @@ def test_committed_bench_line_follows_the_contract(tag):
     if tag != "r01":
         assert d["timed_seconds"] >= 5.0                                       # long enough for the driver's sampler
         assert c["cores"] == c["workers"] >= 1 and c["one_core_value"] > 0     # all-cores figure is measured, not scaled
-        assert r["traffic"] is None or "profiles/" in r["traffic_source"]
+        src = r["traffic_source"]["how"] if isinstance(r.get("traffic_source"), dict) else r.get("traffic_source")
+        assert r["traffic"] is None or "profiles/" in src or src.startswith("measured by this run")
+    if tag >= "r06":
+        # `frac` is the rate on the bytes MOVED, nothing in the line exceeds the copy ceiling unlabelled, the
+        # two-pass accounting has its own name, the kernels carry solo AND in-step durations, configs 3 and 5 ride along
+        assert "moved" in r["frac_basis"] and r["frac"] < r["frac_two_pass_accounting"] and r["frac_of_copy_ceiling"] < 1.0
+        assert abs(r["frac"] - r["traffic"] / (r["solo_ms_per_launch"] * 1e-3) / 8e12) < 1e-9
+        assert d["hbm_frac_of_copy_ceiling"] < 1.0 and d["hbm_two_pass_accounting"]["bytes_per_frame"] > d["hbm_moved_bytes_per_frame"]
+        for fam in ("caf_segments", "caf_doppler", "ls_correlate", "ls_fir_subtract"):
+            k = d["kernels"][fam]
+            assert k["in_step_ms_per_launch"] >= 0.9 * k["avg_ms_per_launch"] and k["moved_bytes_per_launch"] > 0, fam
+        acc = d["kernel_time_accounting"]
+        assert acc["in_step_mean_concurrency"] > 1.0 and acc["solo_sum_ms_per_step"] > 0
+        assert c["cores"] <= c["usable_cores"] <= c["host_cores"] and len(c["legs"]) >= 1
+        assert c["value"] == max(l["value"] for l in c["legs"] if "value" in l)
+        for leg in ("cfg3", "cfg5"):
+            sec = d["secondary"][leg]
+            assert sec["value"] > 0 and sec["unit"] == "frames/s" and "roofline" in sec and leg in sec["workload"]
 
 
 @pytest.mark.parametrize("F", [256, 512, 1024, 2048, 4096])
