@@ -876,6 +876,8 @@ def self_launch(args):
     import socket
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.share_gpu and have >= 1:
+        have = args.gpus                                   # rehearsal: the ranks share what there is
     if have < args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, this host exposes {have} GPU(s): refusing to run a "
                          f"{args.gpus}-GPU benchmark on fewer (no line printed)")
@@ -939,6 +941,14 @@ def main():
     ap.add_argument("--secondary", default="auto", choices=["auto", "cfg3,cfg5", "cfg3", "cfg5", "none"],
                     help="short legs of BASELINE configs 3 and 5 in child processes, reported under `secondary`; auto = both, on the "
                          "default single-GPU cfg2 line only")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of an N > 1 run.  nccl (= RCCL, default) is the product; gloo is a REHEARSAL of "
+                         "the multi-rank control flow where RCCL cannot run (two ranks sharing the one GPU of the test box, "
+                         "--share-gpu): sharding, halo, per-sub-batch gather bookkeeping, part gathers, the rank-0 line -- with "
+                         "real kernels, the maps staged through the host for the gather.  Its line says so and is not a number "
+                         "of record")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rank r uses GPU r mod (number of GPUs): several ranks on one GPU (rehearsal runs only)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-kernel HIP-event section (the counter / trace child passes: every library launch they see "
                          "then belongs to a step)")
@@ -978,11 +988,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:                                    # self_launch() has already refused every way to get here
         raise SystemExit(f"bench.py: --gpus {args.gpus} but {world} rank(s) are running")
+    if args.share_gpu:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    rehearsal = world > 1 and (args.dist_backend != "nccl" or args.share_gpu)
+    # small control tensors of the collectives: on the device for RCCL, on the host for gloo (which moves CUDA tensors only
+    # for broadcast and all_reduce)
+    ctrl = device if args.dist_backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     _lib.require_gpu()
 
     wl = args.workload
@@ -1060,6 +1079,10 @@ def main():
         # through a communicator of ONE rank -- what tests/test_gpu_stream.py runs; not a number of record
         gather_mode = "prc"
     comm = None
+    if rehearsal and gather_mode in ("auto", "prc"):
+        if gather_mode == "prc":
+            raise SystemExit("bench.py: --gather prc needs RCCL ranks on GPUs of their own (not --dist-backend gloo / --share-gpu)")
+        gather_mode = "torch"                           # RCCL refuses two ranks on one GPU; gloo has no RCCL id to share
     if world == 1 and gather_mode == "prc":
         comm = prstream.FrameComm(0, 1, prstream.FrameComm.unique_id())
     elif gather_mode in ("auto", "prc"):
@@ -1071,7 +1094,7 @@ def main():
             if gather_mode == "prc":
                 raise
             print(f"[rank {rank}] prc_comm_create failed ({e}); gathering through torch.distributed", file=sys.stderr)
-        flag = torch.tensor([ok], device=device, dtype=torch.int32)
+        flag = torch.tensor([ok], device=ctrl, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             comm = None
@@ -1219,7 +1242,7 @@ def main():
             t0 = time.perf_counter()
             step()
             fence()
-            probe = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            probe = torch.tensor([time.perf_counter() - t0], device=ctrl, dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(probe, op=dist.ReduceOp.MAX)
             steps = int(min(max(np.ceil(MIN_TIMED_SECONDS / max(float(probe.item()), 1e-6)), 3), 2000))
@@ -1230,7 +1253,7 @@ def main():
     dt = time.perf_counter() - t0
     rank_seconds = [dt]
     if world > 1:
-        mine = torch.tensor([dt], device=device, dtype=torch.float64)
+        mine = torch.tensor([dt], device=ctrl, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)                 # every rank's own clock around the same K steps
         rank_seconds = [float(t.item()) for t in every]
@@ -1245,7 +1268,7 @@ def main():
             print(f"[rank {rank}] prc_comm_count failed: {e}", file=sys.stderr)
             mine_n, mine_r = -1, -1
         sent = float(nframes) * F * (R + 1) * 8.0 if gather_mode != "none" else 0.0
-        info = torch.tensor([float(mine_n), float(mine_r), sent], device=device, dtype=torch.float64)
+        info = torch.tensor([float(mine_n), float(mine_r), sent], device=ctrl, dtype=torch.float64)
         every_info = [torch.zeros_like(info) for _ in range(world)]
         dist.all_gather(every_info, info)
         rccl_seen = [[int(t[0].item()), int(t[1].item())] for t in every_info]
@@ -1263,6 +1286,21 @@ def main():
         np.savez(args.dump, frame_index=np.array(pick), seed0=seed0, nframes=nframes, **extra,
                  **{f"ill{i}_frames": o[pick].cpu().numpy() for i, o in enumerate(last)},
                  **{f"ill{i}_sums": o[:nframes].sum(dim=(1, 2)).cpu().numpy() for i, o in enumerate(last)})
+    if args.dump and world > 1 and rank == 0 and gather_mode != "none" and nill == 1:
+        # N > 1: what ARRIVED on the root.  Strong (cfg4): the assembled stream's maps -- every frame's sum and four picked
+        # maps, comparable with a one-rank --dump of the same stream (sharding + halo + gather end to end).  Weak: the last
+        # gathered block [rank 0's frames | rank 1's | ...] of the step and rank 0's own frames of that sub-batch.
+        drain()
+        torch.cuda.synchronize()
+        if strong:
+            full = recv[((stepno[0] - 1) % nsets) % 2] if args.gather_parts > 1 else recv[last_gather["k"]]
+            pick = sorted({0, min(1, total - 1), total // 2, total - 1})
+            np.savez(args.dump, frame_index=np.array(pick), seed0=seed0, nframes=total, world=world,
+                     ill0_frames=full[pick].cpu().numpy(), ill0_sums=full[:total].sum(dim=(1, 2)).cpu().numpy())
+        elif last_gather:
+            m, f0 = last_gather["m"], last_gather["first"]
+            np.savez(args.dump, world=world, m=m, first=f0, gathered_block=recv[last_gather["k"]][:m * world].cpu().numpy(),
+                     own_frames=outs[(stepno[0] - 1) % nsets][0][f0:f0 + m].cpu().numpy())
 
     # ---- per-kernel timing with HIP events on the launch stream (rank 0) --------------------
     result = None
@@ -1441,6 +1479,9 @@ def main():
                        "doppler_method": {1: "rocfft"}.get(dp, dp),
                        "parallelism": par},
             "timed_seconds": dt,
+            # a rehearsal of the multi-rank control flow (gloo, ranks sharing a GPU): NOT a scaling number
+            "rehearsal": (f"{args.dist_backend} backend, {world} ranks on {torch.cuda.device_count()} GPU(s): control flow only, "
+                          f"not a number of record") if rehearsal else None,
             # which code moved the maps (prc = prc_gather_frames: RCCL send/recv group through the C ABI; torch =
             # torch.distributed.gather; none = single GPU or surfaces stay put) and every rank's own clock
             "gather_path": gather_mode, "rccl_version": _lib.rccl_version() if gather_mode == "prc" else None,

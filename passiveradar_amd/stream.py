@@ -230,6 +230,22 @@ def gather_frames(local, shard, group=None, dst=0, async_op=False, out=None, com
         ev.record(st)
         return res, _StreamWork(ev, send)
     per = max(counts)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # REHEARSAL path (bench.py --dist-backend gloo): gloo gathers host tensors only, so the maps go through the host,
+        # synchronously, on the current stream -- the control flow of a multi-rank run where RCCL cannot be used (ranks
+        # sharing one GPU); never the product path
+        send_h = torch.zeros((per, F, cols, 2), dtype=torch.float32)
+        if counts[me]:
+            send_h[:counts[me]] = torch.view_as_real(local).cpu()
+        recv_h = [torch.empty((per, F, cols, 2), dtype=torch.float32) for _ in range(shard.world)] if on_dst else None
+        dist.gather(send_h, recv_h, dst=dst, group=group)
+        if on_dst:
+            resr, lo = torch.view_as_real(res), 0
+            for r in range(shard.world):
+                if counts[r]:
+                    resr[lo:lo + counts[r]].copy_(recv_h[r][:counts[r]])
+                lo += counts[r]
+        return (res, _NoWork()) if async_op else res
     if counts[me] == per and local.is_contiguous():
         send = torch.view_as_real(local)
     else:

@@ -736,3 +736,62 @@ def _phases_case(C, torch, _lib, engine, scene, n_in, nb):
             buf[b] = 1e9 + b                                   # the caller's memory is reused at once
         torch.cuda.synchronize()
         assert torch.equal(got, want), rounds
+
+
+def _bench_two_ranks_one_gpu(tmp_path, extra, name):
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dump = str(tmp_path / f"{name}.npz")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--share-gpu",
+           "--no-cpu", "--steps", "2", "--warmup", "1", "--dump", dump] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=repo, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and len(line["rank_ms_per_step"]) == 2 and line["gather_path"] == "torch", line
+    assert "not a number of record" in line["rehearsal"] and line["rccl_nranks"] is None
+    assert all(b > 0 for b in line["gathered_bytes_per_rank_per_step"])
+    return line, np.load(dump)
+
+
+def test_bench_two_ranks_rehearsal_strong_scaling_equals_one_rank(tmp_path):
+    """The multi-rank control flow of bench.py has never run on hardware (one GPU per box).  REHEARSAL: two ranks share the
+    one GPU over gloo (`--dist-backend gloo --share-gpu`; RCCL refuses two ranks on one device, so the gather takes the
+    torch path with the maps staged through the host): config 4's stream sharded over the two ranks -- contiguous frame
+    ranges, one halo chunk re-filtered locally, four part gathers per pass overlapped with compute -- must assemble on rank 0
+    into the maps one rank computes alone (main.py:169-194, 213-224): every frame's sum and four picked maps."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    frames = 301
+    line, two = _bench_two_ranks_one_gpu(tmp_path, ["--workload", "cfg4", "--frames", str(frames)], "two")
+    assert line["scaling"] == "strong" and line["config"]["frames_per_step_total"] == frames
+    one_dump = str(tmp_path / "one.npz")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--workload", "cfg4", "--frames", str(frames), "--no-cpu",
+                        "--steps", "2", "--warmup", "1", "--dump", one_dump], capture_output=True, text=True, timeout=1500, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    one = np.load(one_dump)
+    assert list(two["frame_index"]) == list(one["frame_index"]) and int(two["nframes"]) == frames
+    scale = np.abs(one["ill0_frames"]).max()
+    assert np.abs(two["ill0_frames"] - one["ill0_frames"]).max() < 5e-6 * scale      # other LS plan sizes: float32 sums group differently
+    assert rel_err(two["ill0_sums"], one["ill0_sums"]) < 1e-4
+
+
+def test_bench_two_ranks_rehearsal_weak_scaling_gathers_every_sub_batch(tmp_path):
+    """the default workload's N > 1 form: every rank its own frames, one gather per sub-batch issued behind the launch that
+    completes it; the last gathered block on rank 0 is [rank 0's frames | rank 1's frames] of that sub-batch"""
+    line, d = _bench_two_ranks_one_gpu(tmp_path, ["--frames", "600"], "weak")
+    assert line["scaling"] == "weak" and line["config"]["frames_per_step_total"] == 1200
+    m = int(d["m"])
+    blk = d["gathered_block"]
+    assert blk.shape[0] == 2 * m and m == 600 - 512                      # the ragged last sub-batch of 600 = 256 + 256 + 88
+    assert np.array_equal(blk[:m], d["own_frames"])                       # rank 0's block landed first, bit for bit
+    assert np.abs(blk[m:]).max() > 0 and not np.array_equal(blk[m:], blk[:m])   # rank 1's frames (another stream) behind it
