@@ -51,6 +51,21 @@ __device__ __forceinline__ float dpp_f(float x, const int which) {
     return __int_as_float(r);
 }
 typedef float v2f __attribute__((ext_vector_type(2)));
+#ifdef NLMS_PLAIN_FMA       // A/B (round 6): the same multiply-adds, same order, same roundings, as four plain v_fma_f32 instead of two packed
+__device__ __forceinline__ void pk_cmac_conj(v2f& acc, v2f w, v2f u) {
+    acc.x = fmaf(w.x, u.x, acc.x); acc.y = fmaf(w.x, u.y, acc.y);
+    acc.x = fmaf(w.y, u.y, acc.x); acc.y = fmaf(w.y, -u.x, acc.y);
+}
+__device__ __forceinline__ v2f pk_cmul_conj(v2f w, v2f u) {
+    v2f acc = {w.x * u.x, w.x * u.y};
+    acc.x = fmaf(w.y, u.y, acc.x); acc.y = fmaf(w.y, -u.x, acc.y);
+    return acc;
+}
+__device__ __forceinline__ void pk_cmac_bconj(v2f& w, v2f u, v2f c) {
+    w.x = fmaf(c.x, u.x, w.x); w.y = fmaf(c.x, u.y, w.y);
+    w.x = fmaf(c.y, u.y, w.x); w.y = fmaf(c.y, -u.x, w.y);
+}
+#else
 // acc += conj(w) * u :  (acc.x, acc.y) += w.x (u.x, u.y);  (acc.x, acc.y) += w.y (u.y, -u.x)
 __device__ __forceinline__ void pk_cmac_conj(v2f& acc, v2f w, v2f u) {
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n"
@@ -71,6 +86,7 @@ __device__ __forceinline__ void pk_cmac_bconj(v2f& w, v2f u, v2f c) {
                  "v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
                  : "+v"(w) : "v"(u), "v"(c));
 }
+#endif
 
 // a wavefront only orders its own LDS traffic (the hardware keeps one wavefront's LDS operations in order)
 __device__ __forceinline__ void wave_lds_fence() {
