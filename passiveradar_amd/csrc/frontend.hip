@@ -513,6 +513,7 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
 #endif
     const int64_t N0 = (int64_t)blockIdx.x * G;                     // first group of the workgroup
     const int64_t i_w = N0 * a.dn + g.r_first;                      // input index of the window's first sample
+#ifndef FEG_EXP_NOSTAGE              // timing ablation, never shipped: no staging at all (the row loop reads whatever LDS holds)
     switch (a.src) {            // one scalar branch per window, not per sample
         case PRC_RAW_I8: feg_stage<PRC_RAW_I8, NCH>(a, g, X, raw, i_w, blk_phase, tid); break;
         case PRC_RAW_U8: feg_stage<PRC_RAW_U8, NCH>(a, g, X, raw, i_w, blk_phase, tid); break;
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
         case PRC_RAW_F32: feg_stage<PRC_RAW_F32, NCH>(a, g, X, raw, i_w, blk_phase, tid); break;
         default: feg_stage<PRC_RAW_C64, NCH>(a, g, X, raw, i_w, blk_phase, tid);
     }
+#endif
     __syncthreads();
     const float2* xl = NCH == 2 ? X + (lane >> 5) * g.xstride + (lane & 31) * g.lane_stride : X + lane * g.lane_stride;
     v2f acc[NQ];
@@ -534,6 +536,15 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
         if (ntrips == 0) break;
         feg_segment<1, NQ>(a, g, xl, __builtin_amdgcn_readfirstlane((int)g.seg_row0[w][sgm]), ntrips,
                            __builtin_amdgcn_readfirstlane((int)g.seg_code[w][sgm]), acc);
+    }
+#endif
+#ifdef FEG_EXP_NOEPI                  // timing ablation, never shipped: every wavefront stores its own partial sums, nothing is added up
+    {
+        float2* out = a.out + (int64_t)b * a.out_stride;
+        const int64_t m = N0 * a.up + (int64_t)(lane & (G - 1)) * a.up;
+        if (w == 0 && m + NQ <= a.n_out)
+            for (int q = 0; q < NQ; ++q) out[m + q] = make_float2(acc[q].x, acc[q].y);
+        return;
     }
 #endif
     __syncthreads();                                                // the window is dead: its LDS takes the partial sums
