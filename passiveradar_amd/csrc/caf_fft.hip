@@ -152,7 +152,11 @@ __global__ __launch_bounds__(64 * CAFF_WAVES, NLB == 1 ? CAFF_OCC : 2) void caf_
                 else un[r] = make_float2(0.f, 0.f);
             }
             if (HAS_WIN) {
+#ifdef CAFF_EXP_WINSMALL              // timing ablation, never shipped (wrong results): the window read out of its first 8 KB only --
+                const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + (n0 & 1023), clampu(cnt) * 4u);   // what its 4 N bytes per frame cost
+#else
                 const __amdgpu_buffer_rsrc_t rw = prc_rsrc(win + n0, clampu(cnt) * 4u);
+#endif
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (r < 8 || (r < 12 && nz > 8) || nz > 12) wn[r] = prc_buf_load_f32(rw, vo4, 256u * r);
