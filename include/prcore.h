@@ -14,6 +14,7 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Work is enqueued
  *     asynchronously; nothing synchronises unless stated.
  *   - caller owns inputs and outputs; the library owns plans and their workspaces.
+ *   - HOST arrays (names ending in `_host`) are read before the call returns and never afterwards: temporaries are fine.
  *   - every function returns PRC_OK (0) or a negative prc_status; prc_last_error() gives a
  *     thread-local message.  The Python layer maps PRC_ESHAPE to ValueError to keep the
  *     reference's error convention (range_doppler_processing.py:46-49, clutter_removal.py:28-29).
@@ -42,8 +43,9 @@ extern "C" {
 /* zero a descriptor and fill in its header; then set the fields */
 #define PRC_DESC_INIT(d) do { memset(&(d), 0, sizeof(d)); (d).struct_size = (uint32_t)sizeof(d); (d).magic = PRC_DESC_MAGIC; } while (0)
 
-#define PRC_VERSION 600   /* 600: every descriptor (prc_caf_desc, prc_ls_desc, prc_frontend_desc, prc_iir_desc) starts with `struct_size`
-                             (layout break: rebuild hosts; from here on descriptors only grow at the end and an older host keeps working);
+#define PRC_VERSION 600   /* 600: every descriptor (prc_caf_desc, prc_ls_desc, prc_frontend_desc, prc_iir_desc) starts with `struct_size`,
+                             `magic` (layout break: rebuild hosts; from here on descriptors only grow at the end and an older host keeps
+                             working); PRC_OPT_CAF_TEAM8; host arrays passed to an entry point are read before it returns;
                              500: prc_frequency_shift_phases, prc_frontend_execute2, prc_cfar2d_c64, prc_mem_info, PRC_OPT_MARKERS; 401: prc_comm_loopback, PRC_OPT_FE_METHOD, PRC_OPT_CFAR_METHOD; 400: prc_caf_desc.multi, prc_set_option / prc_get_option (no environment variables are read),
                              prc_comm_count; 310: prc_ls_desc.method = 4, NLMS up to 8192 taps */
 
@@ -293,7 +295,8 @@ int prc_frontend_out_len(const prc_frontend_plan* plan, int64_t* n_out);   /* ce
 /* deinterleave_IQ (signal_utils.py:19-22) -> frequency_shift(fc, fs, block phase) (:24-27 with the
  * array phase of main.py:125-149; mix = 0 skips it) -> resample(up, down) (:15-17, padtype 'line'),
  * fused; block b reads raw at b*raw_stride (elements of the raw type) and writes complex64 at
- * b*out_stride.  phases_host: HOST array of nblocks block phase offsets (radians) or NULL. */
+ * b*out_stride.  phases_host: HOST array of nblocks block phase offsets (radians) or NULL; read while the call is being
+ * made (the values travel in the kernel arguments), it may be freed or reused as soon as the call returns. */
 int prc_frontend_execute(prc_frontend_plan* plan, const void* raw, int64_t raw_stride, int32_t mix,
                          double fc, double fs, const double* phases_host, void* out, int64_t out_stride,
                          int32_t nblocks, void* stream);
