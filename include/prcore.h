@@ -113,7 +113,10 @@ typedef enum prc_option {
     PRC_OPT_CAF_TEAM8 = 13,       /* 4096-point CAF segment kernel, read per launch: 0 = teams of four wavefronts, 16 points per
                                      thread (three wavefronts per SIMD); 1 = teams of EIGHT wavefronts, 8 points per thread (six per
                                      SIMD, a third LDS exchange per transform); default: the measured choice  */
-    PRC_OPT_COUNT_ = 14
+    PRC_OPT_FE_FOLD = 14,         /* front-end group kernel, read per launch: 1 (default) = FOLDED tap rows where they apply (odd decimation:
+                                     rows rho and rho + M of the banded tap table never meet the same output, so they share one row of
+                                     full width: 184 rows instead of 294 at 13:119, no multiply-adds on zero taps); 0 = the unfolded rows  */
+    PRC_OPT_COUNT_ = 15
 } prc_option;
 int prc_set_option(int32_t option, int64_t value);     /* PRC_EINVAL for an unknown option or a value out of range */
 int prc_get_option(int32_t option, int64_t* value);

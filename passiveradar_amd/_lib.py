@@ -23,7 +23,7 @@ CAF_MULTI_MODES = {"auto": CAF_MULTI_AUTO, "turns": CAF_MULTI_TURNS, "shared": C
 # prc_option
 (OPT_CAF_MULTI_MODE, OPT_CAF_GROUP_MB, OPT_LS_TEAM_PIECES, OPT_LS_TEAM_ALIGN, OPT_NLMS_WAVES, OPT_LS_CACHE_LIMIT_MB,
  OPT_NLMS_WG_WAVES, OPT_CAF_XCD_CONTIG, OPT_CAF_PAIR_FRAMES, OPT_FE_METHOD,
- OPT_CFAR_METHOD, OPT_MARKERS, OPT_FE_BALANCE, OPT_CAF_TEAM8) = range(14)
+ OPT_CFAR_METHOD, OPT_MARKERS, OPT_FE_BALANCE, OPT_CAF_TEAM8, OPT_FE_FOLD) = range(15)
 CAF_MAX_REFS = 8
 COMM_ID_BYTES = 128
 

@@ -245,6 +245,16 @@ struct FegArgs {
     int32_t lane_stride, pad, span;   // span: staged samples per workgroup (and channel)
     int32_t xstride;                  // two-channel form: LDS elements between the two channels' windows
     float inv_dn;
+    // Round 6: FOLDED rows.  A column of the tap table (one of the `up` outputs of a group) meets a contiguous run of at most
+    // M = max column length rows, and the runs start later for smaller q -- the table is a band: 37 % of T[rows][up] at
+    // 13:119 are zeros in its two corners.  Rows rho and rho + M never both meet the same column, so they FOLD into one row
+    // of M: T2[rho][q] = T[rho][q] or T[rho + M][q], whichever exists, with the input of row rho + M for the columns
+    // q < q0(rho) and the input of row rho for the others.  Every folded row then carries `up` non-zero taps: M rows of
+    // full width instead of rows_total (184 against 294), dealt to the wavefronts in equal runs -- no corner, no imbalance
+    // (round 5's banded windows saved the same multiply-adds and lost them again to uneven wavefronts and odd widths).
+    const float* T2;                  // [fold_M + 3][16]; nullptr: no folded form for this plan
+    int32_t fold_M;                   // 0: the unfolded row loop
+    int16_t fseg_row0[FEG_WAVES][FEG_SEGS], fseg_rows[FEG_WAVES][FEG_SEGS], fseg_q0[FEG_WAVES][FEG_SEGS];
 };
 
 #ifndef FEG_CHUNK
@@ -465,6 +475,65 @@ __device__ __forceinline__ void feg_trips(const FeArgs& a, const FegArgs& g, con
         use(pa, pb, x0, x1);
     }
 }
+// One run of FOLDED rows (FegArgs.T2): `nrows` rows from `row0` on, the columns q < Q0 multiply the input of row + M (xb), the
+// others the input of the row itself (xa).  Only for odd decimations (no pad samples: an input's LDS offset is its row).
+template <int Q0, int NQ>
+__device__ __forceinline__ void feg_rows_folded(const FegArgs& g, const float2* xl, int row0, int nrows, v2f (&acc)[NQ]) {
+    constexpr int NP = (NQ + 1) / 2;                             // tap pairs per row
+    const fe_const_float* tr = (const fe_const_float*)(g.T2 + (size_t)row0 * 16);
+    const float2* xa_p = xl + (g.rows_total - 1 - row0);         // rows only go down: the input of the next row is one sample earlier
+    const float2* xb_p = xa_p - g.fold_M;
+    auto row = [&](const v2f (&pa)[NP], float2 fa, float2 fb) {
+        const v2f xa = v2f{fa.x, fa.y}, xb = v2f{fb.x, fb.y};
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int q = 2 * j;
+            if (q < NQ) {
+                if (q < Q0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[q < NQ ? q : 0]) : "s"(pa[j]), "v"(xb));
+                else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc[q < NQ ? q : 0]) : "s"(pa[j]), "v"(xa));
+            }
+            if (q + 1 < NQ) {
+                if (q + 1 < Q0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[q + 1 < NQ ? q + 1 : 0]) : "s"(pa[j]), "v"(xb));
+                else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc[q + 1 < NQ ? q + 1 : 0]) : "s"(pa[j]), "v"(xa));
+            }
+        }
+    };
+    // two rows per trip (their taps and inputs requested together), then the odd one
+    int r = 0;
+#pragma unroll 1
+    for (; r + 2 <= nrows; r += 2) {
+        const fe_const_v2f* tp = (const fe_const_v2f*)tr;
+        v2f pa[NP], pb[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) { pa[j] = tp[j]; pb[j] = tp[8 + j]; }
+        tr += 32;
+        const float2 fa0 = xa_p[0], fa1 = xa_p[-1];
+        float2 fb0 = fa0, fb1 = fa1;
+        if (Q0 > 0) { fb0 = xb_p[0]; fb1 = xb_p[-1]; }
+        xa_p -= 2;
+        xb_p -= 2;
+        row(pa, fa0, fb0);
+        row(pb, fa1, fb1);
+    }
+    if (r < nrows) {
+        const fe_const_v2f* tp = (const fe_const_v2f*)tr;
+        v2f pa[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) pa[j] = tp[j];
+        const float2 fa = xa_p[0];
+        float2 fb = fa;
+        if (Q0 > 0) fb = xb_p[0];
+        row(pa, fa, fb);
+    }
+}
+template <int Q_, int NQ>
+__device__ __forceinline__ void feg_fold_segment(const FegArgs& g, const float2* xl, int row0, int nrows, int q0, v2f (&acc)[NQ]) {
+    if constexpr (Q_ <= NQ) {
+        if (q0 == Q_) feg_rows_folded<Q_, NQ>(g, xl, row0, nrows, acc);
+        else feg_fold_segment<Q_ + 1, NQ>(g, xl, row0, nrows, q0, acc);
+    }
+}
+
 // the column window of a segment is a compile-time choice among the prefixes [0, w) and the suffixes [NQ - w, NQ)
 template <int W_, int NQ>
 __device__ __forceinline__ void feg_segment(const FeArgs& a, const FegArgs& g, const float2* xl, int row0, int ntrips, int code,
@@ -530,12 +599,22 @@ __global__ __launch_bounds__(FEG_THREADS, 2 * FEG_WAVES / 4) void frontend_group
 #ifdef FEG_EXP_NOFIR                      // timing ablation, never shipped: one trip
     feg_trips<0, NQ, NQ, false>(a, g, xl, 0, 1, acc);
 #else
+    if (g.fold_M > 0) {
 #pragma unroll 1
-    for (int sgm = 0; sgm < FEG_SEGS; ++sgm) {
-        const int ntrips = __builtin_amdgcn_readfirstlane((int)g.seg_trips[w][sgm]);
-        if (ntrips == 0) break;
-        feg_segment<1, NQ>(a, g, xl, __builtin_amdgcn_readfirstlane((int)g.seg_row0[w][sgm]), ntrips,
-                           __builtin_amdgcn_readfirstlane((int)g.seg_code[w][sgm]), acc);
+        for (int sgm = 0; sgm < FEG_SEGS; ++sgm) {
+            const int nrows = __builtin_amdgcn_readfirstlane((int)g.fseg_rows[w][sgm]);
+            if (nrows == 0) break;
+            feg_fold_segment<0, NQ>(g, xl, __builtin_amdgcn_readfirstlane((int)g.fseg_row0[w][sgm]), nrows,
+                                    __builtin_amdgcn_readfirstlane((int)g.fseg_q0[w][sgm]), acc);
+        }
+    } else {
+#pragma unroll 1
+        for (int sgm = 0; sgm < FEG_SEGS; ++sgm) {
+            const int ntrips = __builtin_amdgcn_readfirstlane((int)g.seg_trips[w][sgm]);
+            if (ntrips == 0) break;
+            feg_segment<1, NQ>(a, g, xl, __builtin_amdgcn_readfirstlane((int)g.seg_row0[w][sgm]), ntrips,
+                               __builtin_amdgcn_readfirstlane((int)g.seg_code[w][sgm]), acc);
+        }
     }
 #endif
 #ifdef FEG_EXP_NOEPI                  // timing ablation, never shipped: every wavefront stores its own partial sums, nothing is added up
@@ -582,6 +661,7 @@ struct prc_frontend_plan {
     float* d_taps = nullptr;     // polyphase layout
     double* d_phases = nullptr;  // max_blocks
     float* d_T = nullptr;        // group form: tap rows (nullptr: up > 16 or the window does not fit LDS)
+    float* d_T2 = nullptr;       // folded tap rows (nullptr: even decimation, or the fold does not apply)
     FegArgs g = {};
     size_t g_lds = 0;
     FegArgs g2 = {};             // two-channel form (32 groups per channel and workgroup); g2_lds = 0: not available
@@ -596,6 +676,7 @@ extern "C" int prc_frontend_plan_destroy(prc_frontend_plan* p) {
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_phases) (void)hipFree(p->d_phases);
     if (p->d_T) (void)hipFree(p->d_T);
+    if (p->d_T2) (void)hipFree(p->d_T2);
     delete p;
     return PRC_OK;
 }
@@ -723,6 +804,74 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
             e = hipMalloc(&p->d_T, sizeof(float) * T.size());
             if (e == hipSuccess) e = hipMemcpy(p->d_T, T.data(), sizeof(float) * T.size(), hipMemcpyHostToDevice);
             p->g.T = p->d_T;
+            p->g.T2 = nullptr;
+            p->g.fold_M = 0;
+            memset(p->g.fseg_row0, 0, sizeof(p->g.fseg_row0));
+            memset(p->g.fseg_rows, 0, sizeof(p->g.fseg_rows));
+            memset(p->g.fseg_q0, 0, sizeof(p->g.fseg_q0));
+            // folded rows (FegArgs): odd decimations only (no pad samples between a row's input and the next)
+            if (e == hipSuccess && pad == 0) {
+                auto tap_idx = [&](int64_t row, int64_t q) { return (q + d->n_pre_remove) * dn - up * (r_hi - row); };
+                auto has = [&](int64_t row, int64_t q) { const int64_t i = tap_idx(row, q); return row < nrows && i >= 0 && i < d->ntaps; };
+                int64_t M = 0;                                             // longest column
+                for (int64_t q = 0; q < up; ++q) {
+                    int64_t len = 0;
+                    for (int64_t row = 0; row < nrows; ++row) len += has(row, q) ? 1 : 0;
+                    if (len > M) M = len;
+                }
+                bool ok = M > 0 && nrows <= 2 * M && M + 3 <= 32000;
+                std::vector<float> T2((size_t)(M + 3) * 16, 0.f);
+                std::vector<int> q0s((size_t)(M > 0 ? M : 1), 0);
+                for (int64_t rho = 0; rho < M && ok; ++rho) {
+                    int q0 = 0;                                            // columns [0, q0) take row rho + M, [q0, up) row rho
+                    for (int64_t q = 0; q < up; ++q) {
+                        const bool lo_ = has(rho, q), hi_ = has(rho + M, q);
+                        if (lo_ && hi_) ok = false;                        // cannot happen (a column is at most M rows long)
+                        if (hi_) {
+                            if (q != q0) ok = false;                       // the columns of row rho + M must be a prefix
+                            q0 = (int)q + 1;
+                            T2[(size_t)rho * 16 + q] = d->taps_host[tap_idx(rho + M, q)];
+                        } else if (lo_) {
+                            T2[(size_t)rho * 16 + q] = d->taps_host[tap_idx(rho, q)];
+                        }
+                    }
+                    for (int64_t q = 0; q < q0; ++q)
+                        if (has(rho, q)) ok = false;
+                    q0s[(size_t)rho] = q0;
+#ifdef FEG_EXP_FOLD_ONESEG                 // timing ablation, never shipped (wrong results): every folded row as a one-input row, so that
+                    q0s[(size_t)rho] = 0; //   a wavefront's rows are ONE segment -- what the segment switches cost
+#endif
+                }
+                // equal runs of folded rows per wavefront; inside a run, consecutive rows with the same q0 form a segment
+                int16_t f_row0[FEG_WAVES][FEG_SEGS] = {}, f_rows[FEG_WAVES][FEG_SEGS] = {}, f_q0[FEG_WAVES][FEG_SEGS] = {};
+                if (ok) {
+                    // equal contiguous runs (measured: dealing every wavefront the same mix of two-input and one-input rows
+                    // instead is SLOWER, 6.67 against 6.46 us per block-channel -- one more segment per wavefront costs more
+                    // than the four wavefronts with two LDS reads per row lose)
+                    const int64_t per = (M + FEG_WAVES - 1) / FEG_WAVES;
+                    for (int w = 0; w < FEG_WAVES && ok; ++w) {
+                        int nseg = 0;
+                        for (int64_t rho = w * per; rho < (w + 1) * per && rho < M; ++rho) {
+                            if (nseg > 0 && f_q0[w][nseg - 1] == q0s[(size_t)rho]) ++f_rows[w][nseg - 1];
+                            else if (nseg < FEG_SEGS) {
+                                f_row0[w][nseg] = (int16_t)rho;
+                                f_rows[w][nseg] = 1;
+                                f_q0[w][nseg] = (int16_t)q0s[(size_t)rho];
+                                ++nseg;
+                            } else ok = false;                             // more runs than a wavefront's list holds: no fold
+                        }
+                    }
+                }
+                if (ok) {
+                    e = hipMalloc(&p->d_T2, sizeof(float) * T2.size());
+                    if (e == hipSuccess) e = hipMemcpy(p->d_T2, T2.data(), sizeof(float) * T2.size(), hipMemcpyHostToDevice);
+                    p->g.T2 = p->d_T2;
+                    p->g.fold_M = (int32_t)M;
+                    memcpy(p->g.fseg_row0, f_row0, sizeof(f_row0));
+                    memcpy(p->g.fseg_rows, f_rows, sizeof(f_rows));
+                    memcpy(p->g.fseg_q0, f_q0, sizeof(f_q0));
+                }
+            }
             p->g.rows_total = (int32_t)rows_total;
             memcpy(p->g.seg_row0, seg_row0, sizeof(seg_row0));
             memcpy(p->g.seg_trips, seg_trips, sizeof(seg_trips));
@@ -824,10 +973,12 @@ static int frontend_run(prc_frontend_plan* p, const void* raw, const void* raw2,
     if (raw2 && p->d_T && p->g2_lds && method != 1) {
         // both channels of every block in one workgroup (one rotation factor per input sample for the two of them)
         dim3 grid((unsigned)ceil_div64(p->n_out, (int64_t)(FEG_G / 2) * a.up), (unsigned)nblocks);
+        FegArgs gg = p->g2;
+        if (!prc_opt(PRC_OPT_FE_FOLD)) gg.fold_M = 0;
 #define PRC_FEG2_CASE(Q)                                                                             \
     case Q:                                                                                          \
         if (int rc_ = prc_lds_optin((const void*)frontend_group_kernel<Q, 2>, (int)p->g2_lds)) return rc_; \
-        hipLaunchKernelGGL((frontend_group_kernel<Q, 2>), grid, dim3(FEG_THREADS), p->g2_lds, stream, a, p->g2); \
+        hipLaunchKernelGGL((frontend_group_kernel<Q, 2>), grid, dim3(FEG_THREADS), p->g2_lds, stream, a, gg); \
         break;
         switch (nq) { PRC_FEG2_CASE(4) PRC_FEG2_CASE(8) PRC_FEG2_CASE(13) PRC_FEG2_CASE(16) }
 #undef PRC_FEG2_CASE
@@ -843,10 +994,12 @@ static int frontend_run(prc_frontend_plan* p, const void* raw, const void* raw2,
     }
     if (p->d_T && method != 1) {
         dim3 grid((unsigned)ceil_div64(p->n_out, (int64_t)FEG_G * a.up), (unsigned)nblocks);
+        FegArgs gg = p->g;
+        if (!prc_opt(PRC_OPT_FE_FOLD)) gg.fold_M = 0;
 #define PRC_FEG_CASE(Q)                                                                              \
     case Q:                                                                                          \
         if (int rc_ = prc_lds_optin((const void*)frontend_group_kernel<Q, 1>, (int)p->g_lds)) return rc_; \
-        hipLaunchKernelGGL((frontend_group_kernel<Q, 1>), grid, dim3(FEG_THREADS), p->g_lds, stream, a, p->g);    \
+        hipLaunchKernelGGL((frontend_group_kernel<Q, 1>), grid, dim3(FEG_THREADS), p->g_lds, stream, a, gg);    \
         break;
         switch (nq) { PRC_FEG_CASE(4) PRC_FEG_CASE(8) PRC_FEG_CASE(13) PRC_FEG_CASE(16) }
 #undef PRC_FEG_CASE

@@ -68,7 +68,7 @@ static std::atomic<int64_t> g_opt[PRC_OPT_COUNT_];
 static const int64_t g_opt_default[PRC_OPT_COUNT_] = {
     /* CAF_MULTI_MODE */ PRC_CAF_MULTI_AUTO, /* CAF_GROUP_MB */ 0, /* LS_TEAM_PIECES */ 32, /* LS_TEAM_ALIGN */ 1,
     /* NLMS_WAVES */ 0, /* LS_CACHE_LIMIT_MB */ 0, /* NLMS_WG_WAVES */ 0, /* CAF_XCD_CONTIG */ 0, /* CAF_PAIR_FRAMES */ 1,
-    /* FE_METHOD */ 0, /* CFAR_METHOD */ 0, /* MARKERS */ 0, /* FE_BALANCE */ 0, /* CAF_TEAM8 */ 0};
+    /* FE_METHOD */ 0, /* CFAR_METHOD */ 0, /* MARKERS */ 0, /* FE_BALANCE */ 0, /* CAF_TEAM8 */ 0, /* FE_FOLD */ 1};
 static std::once_flag g_opt_once;
 static void opt_init() {
     std::call_once(g_opt_once, [] { for (int i = 0; i < PRC_OPT_COUNT_; ++i) g_opt[i].store(g_opt_default[i]); });
@@ -95,6 +95,7 @@ extern "C" int prc_set_option(int32_t option, int64_t value) {
         case PRC_OPT_CFAR_METHOD: ok = value == 0 || value == 1; break;
         case PRC_OPT_FE_BALANCE: ok = value >= 0 && value <= 1000; break;
         case PRC_OPT_CAF_TEAM8: ok = value == 0 || value == 1; break;
+        case PRC_OPT_FE_FOLD: ok = value == 0 || value == 1; break;
         case PRC_OPT_MARKERS:
             ok = value == 0 || value == 1;
             if (value == 1 && !roctx_bind()) {

@@ -1236,6 +1236,44 @@ def test_cfar_of_the_complex_map_in_one_kernel(H, W, fw, gw):
         CFAR_2D_abs(X[0, 0], fw, gw)
 
 
+@pytest.mark.parametrize("up,dn", [(13, 119), (3, 7), (16, 15), (7, 45), (2, 9), (5, 4), (1, 5), (12, 7)])
+def test_front_end_folded_tap_rows_give_the_same_samples(up, dn):
+    """PRC_OPT_FE_FOLD (round 6, default 1, read per launch): rows rho and rho + M of the banded tap table never meet the same
+    output of a group, so they share one row of full width (`FegArgs.T2`: 193 rows instead of 304 at 13:119 -- no
+    multiply-adds on the zeros of the table's corners); the columns q < q0(rho) multiply the input of row rho + M, the
+    others the input of row rho.  Odd decimations only (the even ones, which pad the LDS window, keep the unfolded rows:
+    2:9 ... 12:7 here run folded, 5:4 does not).  Same samples as the unfolded rows to float32 rounding (the row sums run
+    in another order), the same as the oracle (signal_utils.py:15-27, main.py:105-166), one and two channels, every raw
+    type, blocks shorter than one window."""
+    import torch
+    from passiveradar_amd import _lib
+    from passiveradar_amd.stream import HipBackend
+    rng = np.random.default_rng(up * 131 + dn)
+    old = _lib.get_option(_lib.OPT_FE_FOLD)
+    try:
+        for dt, n_in, nblk in (("int8", 64 * dn + 37, 3), ("int16", 9001, 2), ("float32", 2 * dn + 3, 4)):
+            if dt == "float32":
+                ra, rb = (rng.standard_normal(2 * n_in * nblk).astype(np.float32) for _ in range(2))
+            else:
+                info = np.iinfo(dt)
+                ra, rb = (rng.integers(info.min, info.max, 2 * n_in * nblk, endpoint=True).astype(dt) for _ in range(2))
+            args = (2 * n_in, 100_000, 2_400_000, up, dn)
+            exp = O.front_end(rb, *args)
+            be = HipBackend(4096, 16, 32, 2.6e5, batch=4, clutter=None)
+            got = {}
+            for fold in (0, 1):
+                _lib.set_option(_lib.OPT_FE_FOLD, fold)
+                one = be.front_end(rb, *args, max_blocks=2)
+                two = be.front_end2(ra, rb, *args, max_blocks=2)[1]
+                torch.cuda.synchronize()
+                assert torch.equal(one, two), (dt, fold)
+                got[fold] = one.cpu().numpy()
+                assert got[fold].shape == exp.shape and rel_err(got[fold], exp) < TIGHT, (dt, fold)
+            assert rel_err(got[1], got[0]) < 2e-6, dt
+    finally:
+        _lib.set_option(_lib.OPT_FE_FOLD, old)
+
+
 @pytest.mark.parametrize("up,dn", [(13, 119), (3, 7), (5, 4), (16, 15), (2, 9)])
 def test_front_end_banded_row_split_gives_the_same_samples(up, dn):
     """PRC_OPT_FE_BALANCE > 0 (an A/B option, read when a front-end plan is made): the group kernel's wavefronts take runs of

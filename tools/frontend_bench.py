@@ -37,7 +37,10 @@ balances = [int(v) for v in os.environ.get("FE_BALANCES", "0,34").split(",")]   
 variants = [("per-output", 1, 0, False)]
 for b in balances:
     variants += [(f"group bal={b}", 2, b, False), (f"group bal={b} x2", 2, b, True)]
-for name, method, balance, two in variants:
+folds = [int(v) for v in os.environ.get("FE_FOLDS", "1").split(",")]        # PRC_OPT_FE_FOLD values (round 6: folded tap rows)
+variants = [(f"{n} fold={f}" if m == 2 else n, m, b, t, f) for (n, m, b, t) in variants for f in (folds if m == 2 else [1])]
+for name, method, balance, two, fold in variants:
+    _lib.set_option(_lib.OPT_FE_FOLD, fold)
     _lib.set_option(_lib.OPT_FE_METHOD, method)
     _lib.set_option(_lib.OPT_FE_BALANCE, balance)
     be = HipBackend(524288, 175, 1024, 262184.87, batch=4, clutter=None)       # a fresh plan: the balance option is read at creation
@@ -49,7 +52,7 @@ for name, method, balance, two in variants:
     outs[name] = out.clone()
     nout = out.shape[0] // nblk
     gflop = nblk * (nout * 4.0 * 2381 / 13 + (icl // 2) * 6.0) / 1e9   # real tap x complex sample multiply-adds on non-zero taps + one rotation product per input
-    print(f"front end {name:15s}: {dt / nblk * 1e6:6.2f} us per block-channel ({icl * nblk / dt / 1e9:.1f} GB/s raw in, "
+    print(f"front end {name:24s}: {dt / nblk * 1e6:6.2f} us per block-channel ({icl * nblk / dt / 1e9:.1f} GB/s raw in, "
           f"{gflop / dt / 1e3:.1f} TFLOP/s of FIR + rotation products)", flush=True)
 _lib.set_option(_lib.OPT_FE_METHOD, 0)
 _lib.set_option(_lib.OPT_FE_BALANCE, 0)
