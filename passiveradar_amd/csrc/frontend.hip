@@ -845,22 +845,35 @@ extern "C" int prc_frontend_plan_create(prc_frontend_plan** plan, const prc_fron
                 // equal runs of folded rows per wavefront; inside a run, consecutive rows with the same q0 form a segment
                 int16_t f_row0[FEG_WAVES][FEG_SEGS] = {}, f_rows[FEG_WAVES][FEG_SEGS] = {}, f_q0[FEG_WAVES][FEG_SEGS] = {};
                 if (ok) {
-                    // equal contiguous runs (measured: dealing every wavefront the same mix of two-input and one-input rows
-                    // instead is SLOWER, 6.67 against 6.46 us per block-channel -- one more segment per wavefront costs more
-                    // than the four wavefronts with two LDS reads per row lose)
-                    const int64_t per = (M + FEG_WAVES - 1) / FEG_WAVES;
+                    // Contiguous runs of about equal COST: a row is one unit, a change of q0 inside a wavefront's run (another
+                    // compile-time split: another loop, 26 accumulator registers copied across, an odd-row tail) about three --
+                    // measured: one segment per wavefront would be 0.7 us per block-channel faster than three.  (Dealing every
+                    // wavefront the same mix of two-input and one-input rows instead is SLOWER, 6.67 against 6.46: one more
+                    // segment for everybody.)
+#ifndef FEG_FOLD_SWITCH_COST
+#define FEG_FOLD_SWITCH_COST 3
+#endif
+                    int64_t total_cost = M;
+                    for (int64_t rho = 1; rho < M; ++rho) total_cost += q0s[(size_t)rho] != q0s[(size_t)rho - 1] ? FEG_FOLD_SWITCH_COST : 0;
+                    int64_t rho = 0, run_cost = 0;
                     for (int w = 0; w < FEG_WAVES && ok; ++w) {
                         int nseg = 0;
-                        for (int64_t rho = w * per; rho < (w + 1) * per && rho < M; ++rho) {
+                        const int64_t until = total_cost * (w + 1) / FEG_WAVES;
+                        while (rho < M) {
+                            const int64_t c = 1 + ((nseg > 0 && f_q0[w][nseg - 1] != q0s[(size_t)rho]) ? FEG_FOLD_SWITCH_COST : 0);
+                            if (w + 1 < FEG_WAVES && nseg > 0 && run_cost + c / 2 > until) break;
                             if (nseg > 0 && f_q0[w][nseg - 1] == q0s[(size_t)rho]) ++f_rows[w][nseg - 1];
                             else if (nseg < FEG_SEGS) {
                                 f_row0[w][nseg] = (int16_t)rho;
                                 f_rows[w][nseg] = 1;
                                 f_q0[w][nseg] = (int16_t)q0s[(size_t)rho];
                                 ++nseg;
-                            } else ok = false;                             // more runs than a wavefront's list holds: no fold
+                            } else { ok = false; break; }                  // more runs than a wavefront's list holds: no fold
+                            run_cost += c;
+                            ++rho;
                         }
                     }
+                    if (rho != M) ok = false;
                 }
                 if (ok) {
                     e = hipMalloc(&p->d_T2, sizeof(float) * T2.size());
